@@ -1,0 +1,218 @@
+/* libmopoe_hip.so -- C ABI of the MI355X (gfx950) MoPoE joint-ELBO hot path.
+ *
+ * The reference (Jimmy2027/MoPoE-MIMIC) is pure Python on PyTorch: it has no FFI.  Each entry point
+ * below names the reference call site(s) whose arithmetic it replaces (paths relative to the
+ * reference repository root); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer into caller-owned memory
+ *     (PyTorch's caching allocator in the shipped host code); the library never allocates, frees or
+ *     retains a pointer past return; outputs and workspaces are caller-allocated.
+ *   - work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no host sync inside.
+ *   - return 0 on success, a negative code on error (mopoe_last_error() gives the text); nothing
+ *     throws across the ABI.
+ *   - activations are fp32, channels-last: a [N,H,W,C] tensor is a row-major [N*H*W, C] matrix
+ *     ("rows" = pixels, "cols" = channels); 1-D sequences use H = 1.  Image inputs/outputs with C = 1
+ *     are therefore bit-identical to the reference's NCHW tensors.
+ *   - conv weights are "packed": Wp[kh*kw][Cin][Cout] (tap-major, Cout contiguous), for Conv and
+ *     ConvTranspose alike (Cin/Cout are those of the FORWARD op).  mimic_amd converts to and from
+ *     the reference's [Cout,Cin,kh,kw] / [Cin,Cout,kh,kw] layouts in state_dict hooks.
+ *   - "stats"/"sums" buffers are double[2*C]: {sum_c, sumsq_c} (or the two BN-backward sums); the
+ *     kernels ACCUMULATE into them with atomics, the caller zeroes them.
+ */
+#ifndef MOPOE_HIP_H
+#define MOPOE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPOE_ABI_VERSION 1
+
+/* error codes */
+#define MOPOE_OK 0
+#define MOPOE_ERR_ARG (-1)     /* inconsistent shapes / unsupported geometry */
+#define MOPOE_ERR_LAUNCH (-2)  /* hipLaunch / hipMemset failed */
+#define MOPOE_ERR_DEVICE (-3)  /* no gfx950 device / wrong arch */
+
+int mopoe_abi_version(void);
+const char* mopoe_last_error(void);
+
+/* Geometry of one Conv{1,2}d / ConvTranspose{1,2}d.  "small" grid = conv output / convT input,
+ * "big" grid = conv input / convT output; big = small*stride - pad + tap. */
+typedef struct {
+  int32_t N;             /* batch */
+  int32_t Hs, Ws;        /* small grid */
+  int32_t Hb, Wb;        /* big grid  */
+  int32_t Cin, Cout;     /* channels of the forward op */
+  int32_t kh, kw;
+  int32_t sh, sw;        /* stride */
+  int32_t ph, pw;        /* padding */
+  int32_t transposed;    /* 0: Conv (big -> small), 1: ConvTranspose (small -> big) */
+} mopoe_conv_geom;
+
+/* A BatchNorm whose normalisation is applied/inverted inside another kernel.
+ * mode 0: absent.  mode 1: batch statistics from `sums` (train).  mode 2: running stats (eval). */
+typedef struct {
+  const double* sums;    /* [2*C] sum, sumsq over `count` rows (mode 1) */
+  const float* gamma;    /* [C] */
+  const float* beta;     /* [C] */
+  const float* rmean;    /* [C] (mode 2) */
+  const float* rvar;     /* [C] (mode 2) */
+  float inv_count;       /* 1 / rows (mode 1) */
+  float eps;
+  int32_t C;
+  int32_t mode;
+} mopoe_bn_ref;
+
+/* dropout multiplier applied in an epilogue: kind 0 none, 1 per-(sample,channel) [N,C]
+ * (nn.Dropout2d), 2 per element [rows,C] (nn.Dropout).  Values are the multiplier itself (0 or 2). */
+typedef struct {
+  const float* mask;
+  int32_t kind;
+  int32_t rows_per_sample;
+} mopoe_mask_ref;
+
+/* ---- convolution family (implicit-GEMM on fp32 MFMA) --------------------------------------------
+ * Replaces torch.nn.Conv1d/Conv2d/ConvTranspose1d/ConvTranspose2d/Linear forward and their autograd
+ * backward as called from mimic/networks/ResidualBlocks.py:20-33,51-65,84-97,118-131,
+ * FeatureExtractorImg.py:61-81, DataGeneratorImg.py:93-98, word_encoding/mmvae_text_enc.py:58-85,
+ * word_encoding/DataGeneratorText.py:83-98, FeatureCompressor.py:21-28,
+ * ConvNetworksImgMimic.py:51-52, ConvNetworksTextMimic.py:57-58.
+ *
+ * y = mask * (conv(act(x)) + bias), act(x) = relu(bn(x)) when bn_in.mode != 0 (the BN -> ReLU that
+ * precedes every conv inside a residual block is fused into the operand load).
+ * out_stats (optional) += {sum, sumsq} of the stored y per output channel. */
+int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y,
+                   const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
+                   double* out_stats, void* stream);
+
+/* dx = d(conv)/d(input) applied to dy.  If relu_bn.mode != 0 the ReLU that fed the conv is inverted in
+ * the epilogue, dx *= [bn(xin) > 0], and bwd_sums (optional) += {sum dx, sum dx*xhat} per input channel
+ * (the two reductions BatchNorm's backward needs), xhat = (xin - mean) * rstd. */
+int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
+                     const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* stream);
+
+/* dwp[kh*kw][Cin][Cout] = d(conv)/d(weight); x is transformed by relu(bn(x)) when bn_in.mode != 0.
+ * dwp is overwritten (the library zero-fills it first when it splits the pixel reduction). */
+int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
+                     const mopoe_bn_ref* bn_in, void* stream);
+
+/* ---- residual-block glue (HBM-bound elementwise + column reductions) -----------------------------
+ * out = a * bn_s(s) + b * m           (ResidualBlocks.py:31-32,63-64,95-96,129-130 with the
+ *                                       shortcut BatchNorm of make_res_block_* fused)
+ * out_stats (optional) += {sum, sumsq} of out (feeds the next block's bn1). */
+int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
+                        const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream);
+
+/* sums += {sum g, sum g*shat} over rows: the reductions for the shortcut BatchNorm's backward. */
+int mopoe_bn_bwd_reduce(const float* g, const float* s, int64_t rows, int32_t C,
+                        const mopoe_bn_ref* bn_s, double* sums, void* stream);
+
+/* backward of mopoe_block_out_fwd:
+ *   dm = b * g * mask                     (gradient w.r.t. the main conv2 output, before dropout2)
+ *   ds = a * BatchNormBackward(g; s)      (gradient w.r.t. the shortcut conv output)
+ *   dgamma_s = a * sums[1], dbeta_s = a * sums[0]
+ * colsum_dm / colsum_ds (optional, float[C], caller-zeroed) += column sums (= conv bias gradients). */
+int mopoe_block_out_bwd(const float* g, const float* s, float* dm, float* ds, int64_t rows, int32_t C,
+                        const mopoe_bn_ref* bn_s, const double* sums, const mopoe_mask_ref* mask,
+                        float a, float b, float* dgamma, float* dbeta, float* colsum_dm,
+                        float* colsum_ds, void* stream);
+
+/* dx = mask * BatchNormBackward(dy; x) + add, with dy already ReLU-masked and sums = {sum dy,
+ * sum dy*xhat} (both from mopoe_conv_dgrad's epilogue).  dgamma = sums[1], dbeta = sums[0].
+ * colsum_dx (optional) += column sums of dx. */
+int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows,
+                       int32_t C, const mopoe_bn_ref* bn, const double* sums,
+                       const mopoe_mask_ref* mask, float* dgamma, float* dbeta, float* colsum_dx,
+                       void* stream);
+
+/* running_mean/var momentum update for `n` BatchNorm layers in one launch (torch.nn.BatchNorm
+ * train-mode side effect).  desc is a device array of n records {sums*, rmean*, rvar*, C, count}. */
+typedef struct {
+  const double* sums;
+  float* rmean;
+  float* rvar;
+  int32_t C;
+  int32_t count;
+} mopoe_bn_running_desc;
+int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_t n, float momentum, void* stream);
+
+/* column sums of a [rows, C] matrix into float out[C] (overwritten). */
+int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream);
+
+/* ---- latent space ----------------------------------------------------------------------------------
+ * One kernel for BaseMMVae.inference's subset loop (mimic/utils/BaseMMVae.py:148-177), mm_div.poe
+ * (evaluation/divergence_measures/mm_div.py:10-17), utils.mixture_component_selection
+ * (utils/utils.py:55-77), calc_group_divergence_moe / calc_kl_divergence (mm_div.py:90-110,
+ * kl_div.py:8-16), losses.calc_klds (evaluation/losses.py:24-31) and utils.reparameterize
+ * (utils/utils.py:45-48).
+ *   mu_in/lv_in[3]: per-modality (mu, logvar) [B,D] in the order PA, Lateral, text; NULL if absent.
+ *   K = number of subsets whose members are all present (order: PA, Lateral, text, Lateral_PA,
+ *       PA_text, Lateral_text, Lateral_PA_text).
+ *   row_start[K+1]: HOST array (copied into the launch), rows [row_start[k], row_start[k+1]) of the
+ *       joint posterior come from subset k (the floor(B*w_k) partition).  w[K]: HOST array of the
+ *       re-normalised mixture weights.
+ *   outputs: mus/lvs [K,B,D]; joint_mu/joint_lv/z [B,D]; klds [K] = KL_k / norm;
+ *       joint_div [1] = sum_k w[k]*klds[k].  eps [B,D] is the N(0,1) noise.  kl_ws: double[K+1]
+ *       workspace that must be zero on entry and is left zero. */
+int mopoe_latent_fwd(const float* const mu_in[3], const float* const lv_in[3], const float* eps,
+                     int32_t B, int32_t D, const int32_t* row_start, const float* w, float norm,
+                     float* mus, float* lvs, float* joint_mu, float* joint_lv, float* z, float* klds,
+                     float* joint_div, double* kl_ws, void* stream);
+
+/* backward: any of g_mus, g_lvs, g_joint_mu, g_joint_lv, g_z, g_klds, g_joint_div may be NULL.
+ * d_mu_in/d_lv_in[3] are overwritten for present modalities. */
+int mopoe_latent_bwd(const float* const mu_in[3], const float* const lv_in[3], const float* eps,
+                     int32_t B, int32_t D, const int32_t* row_start, const float* w, float norm,
+                     const float* g_mus, const float* g_lvs, const float* g_joint_mu,
+                     const float* g_joint_lv, const float* g_z, const float* g_klds,
+                     const float* g_joint_div, float* const d_mu_in[3], float* const d_lv_in[3],
+                     void* stream);
+
+/* ---- likelihoods -----------------------------------------------------------------------------------
+ * Laplace(loc = x_hat, scale): out[0] = -sum log p(x | x_hat) / norm
+ * (modalities/Modality.py:25-30 with dist.Laplace, networks/VAEtrimodalMimic.py:55-57,
+ *  evaluation/losses.py:17).  ws: double[2], zero on entry, left zero. */
+int mopoe_laplace_nll_fwd(const float* x_hat, const float* x, int64_t n, float scale, float norm,
+                          float* out, double* ws, void* stream);
+/* d x_hat = g[0] * sign(x_hat - x) / (scale * norm) */
+int mopoe_laplace_nll_bwd(const float* x_hat, const float* x, const float* g, int64_t n, float scale,
+                          float norm, float* dx_hat, void* stream);
+
+/* row-wise log-softmax over [rows, V] (nn.LogSoftmax(dim=1) of word_encoding/DataGeneratorText.py:77
+ * in channels-last form); y may alias x. */
+int mopoe_logsoftmax_fwd(const float* x, float* y, int64_t rows, int32_t V, void* stream);
+/* dx = dy - exp(y) * rowsum(dy); dx may alias dy. */
+int mopoe_logsoftmax_bwd(const float* dy, const float* y, float* dx, int64_t rows, int32_t V,
+                         void* stream);
+/* OneHotCategorical NLL of float-encoded token ids (modalities/MimicText.py:37-40):
+ * out[0] = -sum_r logp[r, ids[r]] / norm.  ws: double[2], zero on entry, left zero. */
+int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm,
+                        float* out, double* ws, void* stream);
+/* dlogp = -g[0]/norm at [r, ids[r]], zero elsewhere (dlogp is overwritten). */
+int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t rows, int32_t V, float norm,
+                        float* dlogp, void* stream);
+
+/* ---- embedding (word_encoding/mmvae_text_enc.py:27-28,73) ------------------------------------------
+ * out[r, :] = table[(int)ids[r], :]; backward scatter-adds into dtable (overwritten), skipping
+ * padding_idx. */
+int mopoe_embedding_fwd(const float* ids, const float* table, float* out, int64_t rows, int32_t V,
+                        int32_t D, void* stream);
+int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int64_t rows, int32_t V,
+                        int32_t D, int32_t padding_idx, void* stream);
+
+/* ---- profiling support for bench.py ------------------------------------------------------------------
+ * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
+ * stream.  mopoe_prof_collect synchronises those events and returns the number of launches, their
+ * summed duration (ms) and their summed algorithmic FLOPs since the last collect. */
+int mopoe_prof_enable(int32_t on);
+int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPOE_HIP_H */

@@ -1,0 +1,139 @@
+"""Parameter holders and layout conversion.
+
+Inside mimic_amd every conv / linear weight lives in the kernels' packed layout
+Wp[kh*kw][Cin][Cout] (include/mopoe_hip.h); ``state_dict()`` / ``load_state_dict()`` speak the
+reference's layouts and key names, so checkpoints interchange with
+mimic/networks/*.py of the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+
+def pack_weight(w_ref: torch.Tensor, kind: str) -> torch.Tensor:
+    """reference layout -> packed [taps, Cin, Cout].
+    kind: 'conv' [Cout,Cin,*k] | 'convT' [Cin,Cout,*k] | 'linear' [out,in]."""
+    if kind == "linear":
+        return w_ref.t().reshape(1, w_ref.shape[1], w_ref.shape[0]).contiguous()
+    nk = w_ref.dim() - 2
+    kdims = tuple(range(2, 2 + nk))
+    if kind == "conv":
+        p = w_ref.permute(*kdims, 1, 0)
+    else:
+        p = w_ref.permute(*kdims, 0, 1)
+    return p.reshape(-1, p.shape[-2], p.shape[-1]).contiguous()
+
+
+def unpack_weight(wp: torch.Tensor, kind: str, k: Tuple[int, ...]) -> torch.Tensor:
+    """packed [taps, Cin, Cout] -> reference layout."""
+    taps, cin, cout = wp.shape
+    if kind == "linear":
+        return wp.reshape(cin, cout).t().contiguous()
+    w = wp.reshape(*k, cin, cout)
+    nk = len(k)
+    if kind == "conv":
+        return w.permute(nk + 1, nk, *range(nk)).contiguous()
+    return w.permute(nk, nk + 1, *range(nk)).contiguous()
+
+
+class PackedConv(nn.Module):
+    """Weight (+bias) of one Conv / ConvTranspose / Linear in packed layout."""
+
+    def __init__(self, cin: int, cout: int, k: Tuple[int, ...], kind: str, bias: bool):
+        super().__init__()
+        assert kind in ("conv", "convT", "linear")
+        self.cin, self.cout, self.k, self.kind = cin, cout, tuple(k), kind
+        taps = math.prod(k) if k else 1
+        self.weight = nn.Parameter(torch.empty(taps, cin, cout))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same distribution as torch's default conv/linear init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)),
+        # with torch's fan_in convention (weight.size(1) * prod(k))
+        taps = self.weight.shape[0]
+        fan_in = (self.cout if self.kind == "convT" else self.cin) * taps
+        bound = 1.0 / math.sqrt(fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def ref_weight(self) -> torch.Tensor:
+        return unpack_weight(self.weight.detach(), self.kind, self.k)
+
+    def ref_grad(self):
+        return None if self.weight.grad is None else unpack_weight(self.weight.grad, self.kind, self.k)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        destination[prefix + "weight"] = self.ref_weight()
+        if self.bias is not None:
+            destination[prefix + "bias"] = self.bias if keep_vars else self.bias.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "weight"
+        if key in state_dict:
+            w = state_dict[key]
+            expect = tuple(unpack_weight(torch.empty(self.weight.shape, device="meta"), self.kind, self.k).shape)
+            if tuple(w.shape) == expect:
+                state_dict[key] = pack_weight(w, self.kind)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+
+class BnParams(nn.Module):
+    """Affine parameters + running statistics of one BatchNorm (same keys as torch.nn.BatchNorm*d)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+        self.pending_batches = 0  # host-side count; avoids one tiny device kernel per BN per step
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self.pending_batches:
+            self.num_batches_tracked += self.pending_batches
+            self.pending_batches = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class Indexed(nn.Module):
+    """Container whose children are named '0', '1', ... (the key scheme nn.Sequential produces)."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+
+class ResBlockParams(nn.Module):
+    """Parameters of one residual block (ResidualBlocks.py of the reference): conv1 (1x1), bn1, bn2,
+    conv2 (k4) and the projection shortcut (conv k4 + BN) under 'downsample' or 'upsample'."""
+
+    def __init__(self, cin: int, cout: int, k: Tuple[int, ...], transposed: bool, main_bias: bool, short_name: str):
+        super().__init__()
+        kind = "convT" if transposed else "conv"
+        self.conv1 = PackedConv(cin, cin, (1,) * len(k), kind, main_bias)
+        self.bn1 = BnParams(cin)
+        self.bn2 = BnParams(cin)
+        self.conv2 = PackedConv(cin, cout, k, kind, main_bias)
+        self.add_module(short_name, Indexed(PackedConv(cin, cout, k, kind, True), BnParams(cout)))
+        self.short_name = short_name
+
+    @property
+    def short(self):
+        return self._modules[self.short_name]

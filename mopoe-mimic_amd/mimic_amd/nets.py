@@ -1,0 +1,434 @@
+"""The four encoder / decoder networks of the MoPoE-MIMIC model as HIP-op chains.
+
+Same constructor signatures, forward signatures, attribute names and state_dict keys as the
+reference classes they stand in for:
+    EncoderImg / DecoderImg     mimic/networks/ConvNetworksImgMimic.py:20-54
+                                (FeatureExtractorImg.py:23-81, DataGeneratorImg.py:29-98)
+    EncoderText / DecoderText   mimic/networks/ConvNetworksTextMimic.py:11-68
+                                (word_encoding/mmvae_text_enc.py:22-85, word_encoding/DataGeneratorText.py:29-98)
+Each network is ONE autograd node: its forward launches the op chain and keeps what the hand-written
+backward needs; its backward launches the dgrad / wgrad / BN-backward chain and returns the gradient
+of every parameter (packed layout) at once.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layout import BnParams, Indexed, PackedConv, ResBlockParams
+from .ops import Geom
+from .trunk import (BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed, trunk_backward,
+                    trunk_forward)
+
+
+def _lin_geom(cin, cout):
+    return Geom(1, 1, 1, 1, 1, cin, cout, 1, 1, 1, 1, 0, 0, False)
+
+
+class _NetFn(torch.autograd.Function):
+    """forward(net, n_inputs, *inputs, *params) -> outputs of net._run_forward."""
+
+    @staticmethod
+    def forward(ctx, net, n_in, *tensors):
+        inputs = tensors[:n_in]
+        outs, saved = net._run_forward(*inputs)
+        ctx.net, ctx.saved, ctx.n_in = net, saved, n_in
+        ctx.in_needs_grad = [isinstance(t, torch.Tensor) and t.requires_grad for t in inputs]
+        return outs if isinstance(outs, tuple) else (outs,)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        net = ctx.net
+        gouts = [None if g is None else g.contiguous() for g in gouts]
+        gin, grads = net._run_backward(ctx.saved, ctx.in_needs_grad, *gouts)
+        ctx.saved = None
+        plist = [grads.get(name) for name, _ in net._named_param_list()]
+        return (None, None, *gin, *plist)
+
+
+class _HipNet(nn.Module):
+    """Shared plumbing: parameter ordering, mask source, running-stat updates."""
+
+    mask_source: MaskSource = MaskSource()
+    dropout_enabled = True  # tests switch this off to reproduce the 'train_nodrop' fixtures
+
+    def _named_param_list(self):
+        if getattr(self, "_plist", None) is None:
+            self._plist = [(n, p) for n, p in self.named_parameters()]
+        return self._plist
+
+    def _call(self, *inputs):
+        params = [p for _, p in self._named_param_list()]
+        return _NetFn.apply(self, len(inputs), *inputs, *params)
+
+    def _dropout_on(self):
+        return self.training and self.dropout_enabled
+
+    def _arena(self, blocks, device):
+        return StatsArena(stats_needed(blocks), device, self.training)
+
+
+# =================================================================================================
+# image encoder
+# =================================================================================================
+class _FeatureExtractorImg(nn.Module):
+    def __init__(self, flags):
+        super().__init__()
+        d, s = flags.DIM_img, flags.img_size
+        self.conv1 = PackedConv(flags.image_channels, d, (3, 3), "conv", False)
+        plan = [(d, 2 * d, 2, 1), (2 * d, 3 * d, 2, 1), (3 * d, 4 * d, 2, 1)]
+        if s == 64:
+            plan += [(4 * d, 5 * d, 2, 0)]
+        elif s == 128:
+            plan += [(4 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 0)]
+        elif s == 256:
+            plan += [(4 * d, 5 * d, 4, 1), (5 * d, 5 * d, 2, 0)]
+        else:
+            raise AttributeError("img_size must be one of 64, 128, 256")
+        self.plan = plan
+        for i, (ci, co, _st, _pd) in enumerate(plan):
+            self.add_module(f"resblock_{i + 1}", Indexed(ResBlockParams(ci, co, (4, 4), False, False, "downsample")))
+
+
+class _Compressor(nn.Module):
+    """LinearFeatureCompressor (FeatureCompressor.py:4-28) without the style branch."""
+
+    def __init__(self, cin, style_dim, cout):
+        super().__init__()
+        if style_dim:
+            raise NotImplementedError("factorized_representation / style latents are out of scope (SURVEY §2.1-4)")
+        self.style_mu = None
+        self.style_logvar = None
+        self.content_mu = PackedConv(cin, cout, (), "linear", True)
+        self.content_logvar = PackedConv(cin, cout, (), "linear", True)
+
+
+def _compress_fwd(comp: _Compressor, feat, batch):
+    g = _lin_geom(comp.content_mu.cin, comp.content_mu.cout).with_batch(batch)
+    mu = ops.conv_fwd(feat, comp.content_mu.weight, g, bias=comp.content_mu.bias)
+    lv = ops.conv_fwd(feat, comp.content_logvar.weight, g, bias=comp.content_logvar.bias)
+    return mu.view(batch, -1), lv.view(batch, -1), g
+
+
+def _compress_bwd(comp: _Compressor, feat, g, gmu, glv, grads, prefix):
+    batch = feat.shape[0]
+    dfeat = None
+    for name, mod, gg in (("content_mu", comp.content_mu, gmu), ("content_logvar", comp.content_logvar, glv)):
+        if gg is None:
+            continue
+        gg4 = gg.reshape(batch, 1, 1, -1)
+        grads[f"{prefix}.{name}.weight"] = ops.conv_wgrad(feat, gg4, g)
+        grads[f"{prefix}.{name}.bias"] = ops.colsum(gg4)
+        d = ops.conv_dgrad(gg4, mod.weight, g)
+        dfeat = d if dfeat is None else dfeat.add_(d)
+    return dfeat
+
+
+class EncoderImg(_HipNet):
+    def __init__(self, flags, style_dim):
+        super().__init__()
+        if getattr(flags, "feature_extractor_img", "resnet") != "resnet":
+            raise NotImplementedError("only feature_extractor_img='resnet' is in scope (SURVEY §2.1-8)")
+        self.flags = flags
+        self.feature_extractor = _FeatureExtractorImg(flags)
+        self.feature_compressor = _Compressor(5 * flags.DIM_img, style_dim, flags.class_dim)
+        s, d = flags.img_size, flags.DIM_img
+        self.stem_geom = Geom(1, s // 2, s // 2, s, s, flags.image_channels, d, 3, 3, 2, 2, 1, 1, False)
+        self.blocks: List[BlockSpec] = []
+        h = s // 2
+        for i, (ci, co, st, pd) in enumerate(self.feature_extractor.plan):
+            ho = (h + 2 * pd - 4) // st + 1
+            g1 = Geom(1, h, h, h, h, ci, ci, 1, 1, 1, 1, 0, 0, False)
+            g2 = Geom(1, ho, ho, h, h, ci, co, 4, 4, st, st, pd, pd, False)
+            blk = getattr(self.feature_extractor, f"resblock_{i + 1}")[0]
+            self.blocks.append(BlockSpec(blk, g1, g2, True, f"feature_extractor.resblock_{i + 1}.0"))
+            h = ho
+        assert h == 1
+
+    def forward(self, x_img):
+        mu, lv = self._call(x_img)
+        return mu, lv
+
+    def _run_forward(self, x_img):
+        b = x_img.shape[0]
+        fe = self.feature_extractor
+        x = x_img.reshape(b, x_img.shape[2], x_img.shape[3], x_img.shape[1]) if x_img.shape[1] == 1 \
+            else x_img.permute(0, 2, 3, 1).contiguous()
+        x = x.contiguous()
+        arena = self._arena(self.blocks, x.device)
+        gs = self.stem_geom.with_batch(b)
+        st0 = arena.take(gs.Cout)
+        h0 = ops.conv_fwd(x, fe.conv1.weight, gs, out_stats=st0)
+        feat, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
+                                             self.mask_source, arena, b)
+        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b)
+        if self.training:
+            apply_running_updates(running)
+        return (mu, lv), dict(x=x, feat=feat, trunk=saved, gs=gs, gl=gl, arena=arena)
+
+    def _run_backward(self, sv, in_needs_grad, gmu, glv):
+        grads: Dict[str, torch.Tensor] = {}
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
+        g0 = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["x"], g0, sv["gs"])
+        gx = None
+        if in_needs_grad[0]:
+            gx = ops.conv_dgrad(g0, self.feature_extractor.conv1.weight, sv["gs"])
+            gx = gx.reshape(gx.shape[0], 1, gx.shape[1], gx.shape[2]) if gx.shape[3] == 1 else gx.permute(0, 3, 1, 2)
+        return [gx], grads
+
+
+# =================================================================================================
+# image decoder
+# =================================================================================================
+class _DataGeneratorImg(nn.Module):
+    def __init__(self, flags):
+        super().__init__()
+        d, s = flags.DIM_img, flags.img_size
+        plan = [(5 * d, 4 * d, 1, 0), (4 * d, 3 * d, 2, 1), (3 * d, 2 * d, 2, 1), (2 * d, d, 2, 1)]
+        if s == 128:
+            plan += [(d, d, 2, 1)]
+        if s == 256:
+            plan += [(d, d, 2, 1), (d, d, 2, 1)]
+        self.plan = plan
+        mods = [Indexed(ResBlockParams(ci, co, (4, 4), True, False, "upsample")) for ci, co, _s, _p in plan]
+        mods.append(PackedConv(d, flags.image_channels, (3, 3), "convT", True))
+        self.generator = Indexed(*mods)
+
+
+class DecoderImg(_HipNet):
+    LAPLACE_SCALE = 0.75  # ConvNetworksImgMimic.py:54
+
+    def __init__(self, flags, style_dim):
+        super().__init__()
+        if style_dim:
+            raise NotImplementedError("style latents are out of scope (SURVEY §2.1-4)")
+        self.flags = flags
+        d = flags.DIM_img
+        self.feature_generator = PackedConv(flags.class_dim, 5 * d, (), "linear", True)
+        self.img_generator = _DataGeneratorImg(flags)
+        self.blocks: List[BlockSpec] = []
+        h = 1
+        for i, (ci, co, st, pd) in enumerate(self.img_generator.plan):
+            ho = (h - 1) * st - 2 * pd + 4
+            # a k4/s1/p0 transposed conv on a 1x1 input equals a k4/s4/p0 one: 16 one-tap phases
+            st_eff = 4 if (st == 1 and h == 1) else st
+            g1 = Geom(1, h, h, h, h, ci, ci, 1, 1, 1, 1, 0, 0, True)
+            g2 = Geom(1, h, h, ho, ho, ci, co, 4, 4, st_eff, st_eff, pd, pd, True)
+            blk = self.img_generator.generator[i][0]
+            self.blocks.append(BlockSpec(blk, g1, g2, True, f"img_generator.generator.{i}.0"))
+            h = ho
+        self.head_geom = Geom(1, h, h, 2 * h, 2 * h, d, flags.image_channels, 3, 3, 2, 2, 1, 1, True)
+        assert 2 * h == flags.img_size
+        self._scale_cache = {}
+
+    @property
+    def head(self):
+        return self.img_generator.generator[len(self.img_generator.plan)]
+
+    def _scale(self, device):
+        key = (device.type, device.index)
+        if key not in self._scale_cache:
+            t = torch.tensor(self.LAPLACE_SCALE, device=device)
+            t._mopoe_const = self.LAPLACE_SCALE
+            self._scale_cache[key] = t
+        return self._scale_cache[key]
+
+    def forward(self, z_style, z_content):
+        (img,) = self._call(z_content)
+        return img, self._scale(img.device)
+
+    def _run_forward(self, z):
+        b = z.shape[0]
+        z4 = z.contiguous().view(b, 1, 1, -1)
+        arena = self._arena(self.blocks, z.device)
+        gl = _lin_geom(self.feature_generator.cin, self.feature_generator.cout).with_batch(b)
+        st0 = arena.take(gl.Cout)
+        h0 = ops.conv_fwd(z4, self.feature_generator.weight, gl, bias=self.feature_generator.bias, out_stats=st0)
+        ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
+                                           self.mask_source, arena, b)
+        gh = self.head_geom.with_batch(b)
+        img = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
+        if self.training:
+            apply_running_updates(running)
+        c = img.shape[3]
+        img = img.view(b, 1, img.shape[1], img.shape[2]) if c == 1 else img.permute(0, 3, 1, 2).contiguous()
+        return (img,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, arena=arena)
+
+    def _run_backward(self, sv, in_needs_grad, gimg):
+        grads: Dict[str, torch.Tensor] = {}
+        b = gimg.shape[0]
+        g4 = gimg.reshape(b, gimg.shape[2], gimg.shape[3], 1) if gimg.shape[1] == 1 \
+            else gimg.permute(0, 2, 3, 1).contiguous()
+        k = len(self.blocks)
+        grads[f"img_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], g4, sv["gh"])
+        grads[f"img_generator.generator.{k}.bias"] = ops.colsum(g4)
+        dht = ops.conv_dgrad(g4, self.head.weight, sv["gh"])
+        g0 = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
+        grads["feature_generator.bias"] = ops.colsum(g0)
+        gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
+        return [gz], grads
+
+
+# =================================================================================================
+# text encoder (word encoding, len_sequence = 128)
+# =================================================================================================
+class _Embedding(nn.Module):
+    def __init__(self, vocab, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(vocab, dim))
+        with torch.no_grad():
+            self.weight[0].zero_()  # padding_idx = 0 (mmvae_text_enc.py:27-28)
+
+
+class _FeatureExtractorText(nn.Module):
+    def __init__(self, flags):
+        super().__init__()
+        d = flags.DIM_text
+        self.embedding = _Embedding(flags.vocab_size, d)
+        self.conv1 = PackedConv(d, d, (4,), "conv", True)
+        self.plan = [(d, 2 * d, 2, 1), (2 * d, 3 * d, 2, 1), (3 * d, 4 * d, 2, 1), (4 * d, 4 * d, 2, 1),
+                     (4 * d, 4 * d, 2, 1), (4 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 0)]
+        for i, (ci, co, _s, _p) in enumerate(self.plan):
+            self.add_module(f"resblock_{i + 1}", Indexed(ResBlockParams(ci, co, (4,), False, True, "downsample")))
+
+
+class EncoderText(_HipNet):
+    def __init__(self, flags, style_dim):
+        super().__init__()
+        if flags.text_encoding != "word":
+            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
+        self.args = flags
+        self.feature_extractor = _FeatureExtractorText(flags)
+        self.feature_compressor = _Compressor(5 * flags.DIM_text, style_dim, flags.class_dim)
+        d, length = flags.DIM_text, flags.len_sequence
+        self.stem_geom = Geom(1, 1, length // 2, 1, length, d, d, 1, 4, 1, 2, 0, 1, False)
+        n_run = 8 if length > 500 else 6  # mmvae_text_enc.py:82-84: resblock_7/8 stay unused at L=128
+        self.blocks: List[BlockSpec] = []
+        w = length // 2
+        for i in range(n_run):
+            ci, co, st, pd = self.feature_extractor.plan[i]
+            wo = (w + 2 * pd - 4) // st + 1
+            g1 = Geom(1, 1, w, 1, w, ci, ci, 1, 1, 1, 1, 0, 0, False)
+            g2 = Geom(1, 1, wo, 1, w, ci, co, 1, 4, 1, st, 0, pd, False)
+            blk = getattr(self.feature_extractor, f"resblock_{i + 1}")[0]
+            self.blocks.append(BlockSpec(blk, g1, g2, False, f"feature_extractor.resblock_{i + 1}.0"))
+            w = wo
+        assert w == 1, "text encoder must reduce the sequence to length 1"
+
+    def forward(self, x_text):
+        mu, lv = self._call(x_text)
+        return mu, lv
+
+    def _run_forward(self, ids):
+        b, length = ids.shape
+        fe = self.feature_extractor
+        ids = ids.contiguous()
+        emb = ops.embedding_fwd(ids, fe.embedding.weight).view(b, 1, length, -1)
+        arena = self._arena(self.blocks, ids.device)
+        gs = self.stem_geom.with_batch(b)
+        st0 = arena.take(gs.Cout)
+        h0 = ops.conv_fwd(emb, fe.conv1.weight, gs, bias=fe.conv1.bias, out_stats=st0)
+        feat, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
+                                             self.mask_source, arena, b)
+        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b)
+        if self.training:
+            apply_running_updates(running)
+        return (mu, lv), dict(ids=ids, emb=emb, feat=feat, trunk=saved, gs=gs, gl=gl, arena=arena)
+
+    def _run_backward(self, sv, in_needs_grad, gmu, glv):
+        grads: Dict[str, torch.Tensor] = {}
+        fe = self.feature_extractor
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
+        g0 = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, sv["gs"])
+        grads["feature_extractor.conv1.bias"] = ops.colsum(g0)
+        demb = ops.conv_dgrad(g0, fe.conv1.weight, sv["gs"])
+        grads["feature_extractor.embedding.weight"] = ops.embedding_bwd(sv["ids"], demb, fe.embedding.weight.shape[0], 0)
+        return [None], grads
+
+
+# =================================================================================================
+# text decoder
+# =================================================================================================
+class _DataGeneratorText(nn.Module):
+    def __init__(self, flags):
+        super().__init__()
+        d = flags.DIM_text
+        if flags.len_sequence != 128:
+            raise NotImplementedError("the output shapes of this network only work for len_sequence 128 here")
+        if getattr(flags, "text_gen_lastlayer", "softmax") != "softmax":
+            raise NotImplementedError("only text_gen_lastlayer='softmax' is in scope")
+        self.plan = [(5 * d, 5 * d, 1, 0), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 4 * d, 2, 1),
+                     (4 * d, 4 * d, 2, 1), (4 * d, d, 2, 1)]
+        mods = [Indexed(ResBlockParams(ci, co, (4,), True, True, "upsample")) for ci, co, _s, _p in self.plan]
+        mods.append(PackedConv(d, flags.vocab_size, (1,), "conv", True))
+        self.generator = Indexed(*mods)
+
+
+class DecoderText(_HipNet):
+    def __init__(self, flags, style_dim):
+        super().__init__()
+        if style_dim:
+            raise NotImplementedError("style latents are out of scope (SURVEY §2.1-4)")
+        if flags.text_encoding != "word":
+            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
+        self.flags = flags
+        d = flags.DIM_text
+        self.feature_generator = PackedConv(flags.class_dim, 5 * d, (), "linear", True)
+        self.text_generator = _DataGeneratorText(flags)
+        self.blocks: List[BlockSpec] = []
+        w = 1
+        for i, (ci, co, st, pd) in enumerate(self.text_generator.plan):
+            wo = (w - 1) * st - 2 * pd + 4
+            st_eff = 4 if (st == 1 and w == 1) else st
+            g1 = Geom(1, 1, w, 1, w, ci, ci, 1, 1, 1, 1, 0, 0, True)
+            g2 = Geom(1, 1, w, 1, wo, ci, co, 1, 4, 1, st_eff, 0, pd, True)
+            blk = self.text_generator.generator[i][0]
+            self.blocks.append(BlockSpec(blk, g1, g2, False, f"text_generator.generator.{i}.0"))
+            w = wo
+        assert w == flags.len_sequence
+        self.head_geom = Geom(1, 1, w, 1, w, d, flags.vocab_size, 1, 1, 1, 1, 0, 0, False)
+
+    @property
+    def head(self):
+        return self.text_generator.generator[len(self.text_generator.plan)]
+
+    def forward(self, z_style, z_content):
+        (logp,) = self._call(z_content)
+        return [logp]
+
+    def _run_forward(self, z):
+        b = z.shape[0]
+        z4 = z.contiguous().view(b, 1, 1, -1)
+        arena = self._arena(self.blocks, z.device)
+        gl = _lin_geom(self.feature_generator.cin, self.feature_generator.cout).with_batch(b)
+        st0 = arena.take(gl.Cout)
+        h0 = ops.conv_fwd(z4, self.feature_generator.weight, gl, bias=self.feature_generator.bias, out_stats=st0)
+        ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
+                                           self.mask_source, arena, b)
+        gh = self.head_geom.with_batch(b)
+        logits = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
+        logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
+        if self.training:
+            apply_running_updates(running)
+        return (logp,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logp=logp, arena=arena)
+
+    def _run_backward(self, sv, in_needs_grad, glogp):
+        grads: Dict[str, torch.Tensor] = {}
+        b = glogp.shape[0]
+        gh = sv["gh"]
+        glogits = ops.logsoftmax_bwd(glogp, sv["logp"]).view(b, 1, gh.Ws, gh.Cout)
+        k = len(self.blocks)
+        grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
+        grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)
+        dht = ops.conv_dgrad(glogits, self.head.weight, gh)
+        g0 = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
+        grads["feature_generator.bias"] = ops.colsum(g0)
+        gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
+        return [gz], grads

@@ -1,0 +1,417 @@
+"""ctypes binding of libmopoe_hip.so (include/mopoe_hip.h): the ONLY compute backend of mimic_amd.
+
+There is deliberately no CPU / eager fallback here: if the HIP library is missing or the tensors are
+not on a GPU the ops raise.  (CPU tests of the host logic monkeypatch this module's functions with
+the torch emulation under tests/, which is test infrastructure, not a product path.)
+
+Every function takes/returns channels-last fp32 tensors (see the header for the layout contract).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")
+ABI_VERSION = 1
+
+RES_A, RES_B = 2.0, 0.3
+BN_EPS = 1e-5
+SUBSET_MASKS = (1, 2, 4, 3, 5, 6, 7)  # bit0 PA, bit1 Lateral, bit2 text; reference subset order
+
+
+class MopoeHipError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------------------------
+# plain-data descriptors shared with the C ABI
+# ----------------------------------------------------------------------------------------------
+class _Geom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "Hs", "Ws", "Hb", "Wb", "Cin", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")]
+
+
+class _BnRef(C.Structure):
+    _fields_ = [("sums", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rmean", C.c_void_p),
+                ("rvar", C.c_void_p), ("inv_count", C.c_float), ("eps", C.c_float), ("C", C.c_int32),
+                ("mode", C.c_int32)]
+
+
+class _MaskRef(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("kind", C.c_int32), ("rows_per_sample", C.c_int32)]
+
+
+class _RunDesc(C.Structure):
+    _fields_ = [("sums", C.c_void_p), ("rmean", C.c_void_p), ("rvar", C.c_void_p), ("C", C.c_int32),
+                ("count", C.c_int32)]
+
+
+@dataclass(frozen=True)
+class Geom:
+    """Conv / ConvTranspose geometry; 'small' grid = conv output / convT input (header: mopoe_conv_geom)."""
+    N: int
+    Hs: int
+    Ws: int
+    Hb: int
+    Wb: int
+    Cin: int
+    Cout: int
+    kh: int
+    kw: int
+    sh: int
+    sw: int
+    ph: int
+    pw: int
+    transposed: bool
+
+    @property
+    def in_shape(self):
+        return (self.N, self.Hs, self.Ws, self.Cin) if self.transposed else (self.N, self.Hb, self.Wb, self.Cin)
+
+    @property
+    def out_shape(self):
+        return (self.N, self.Hb, self.Wb, self.Cout) if self.transposed else (self.N, self.Hs, self.Ws, self.Cout)
+
+    @property
+    def taps(self):
+        return self.kh * self.kw
+
+    def with_batch(self, n):
+        return Geom(n, *[getattr(self, f) for f in
+                         ("Hs", "Ws", "Hb", "Wb", "Cin", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")])
+
+    def c(self):
+        return _Geom(self.N, self.Hs, self.Ws, self.Hb, self.Wb, self.Cin, self.Cout, self.kh, self.kw,
+                     self.sh, self.sw, self.ph, self.pw, int(self.transposed))
+
+
+@dataclass
+class Bn:
+    """A BatchNorm to be applied / inverted inside another kernel (header: mopoe_bn_ref)."""
+    gamma: torch.Tensor
+    beta: torch.Tensor
+    mode: int                               # 1 batch statistics, 2 running statistics
+    sums: Optional[torch.Tensor] = None     # double [2, C] (mode 1)
+    count: int = 0                          # rows the sums were taken over (mode 1)
+    rmean: Optional[torch.Tensor] = None
+    rvar: Optional[torch.Tensor] = None
+    eps: float = BN_EPS
+
+    def c(self):
+        return _BnRef(_p(self.sums), _p(self.gamma), _p(self.beta), _p(self.rmean), _p(self.rvar),
+                      (1.0 / self.count) if self.count else 0.0, self.eps, self.gamma.numel(), self.mode)
+
+
+@dataclass
+class Mask:
+    """Dropout multiplier (values 0 or 2).  kind 1: [N, C] per-sample channel mask (nn.Dropout2d);
+    kind 2: [rows, C] elementwise (nn.Dropout)."""
+    mask: torch.Tensor
+    kind: int
+    rows_per_sample: int = 1
+
+    def c(self):
+        return _MaskRef(_p(self.mask), self.kind, self.rows_per_sample)
+
+
+_NO_BN = _BnRef(None, None, None, None, None, 0.0, 0.0, 0, 0)
+_NO_MASK = _MaskRef(None, 0, 1)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------
+# library loading
+# ----------------------------------------------------------------------------------------------
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MopoeHipError(f"{LIB_PATH} not built: run `python __graft_entry__.py build` "
+                                "(mimic_amd has no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mopoe_last_error.restype = C.c_char_p
+        _lib.mopoe_abi_version.restype = C.c_int
+        if _lib.mopoe_abi_version() != ABI_VERSION:
+            raise MopoeHipError("libmopoe_hip.so ABI version mismatch")
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise MopoeHipError(f"libmopoe_hip error {rc}: {lib().mopoe_last_error().decode()}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise MopoeHipError("mimic_amd ops need GPU tensors (no CPU fallback)")
+            if not t.is_contiguous():
+                raise MopoeHipError("mimic_amd ops need contiguous tensors")
+
+
+def _bn(bn: Optional[Bn]):
+    return C.byref(bn.c()) if bn is not None else C.byref(_NO_BN)
+
+
+def _mask(m: Optional[Mask]):
+    return C.byref(m.c()) if m is not None else C.byref(_NO_MASK)
+
+
+def new_stats(n_channels: int, device) -> torch.Tensor:
+    return torch.zeros(2, n_channels, dtype=torch.float64, device=device)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution family
+# ----------------------------------------------------------------------------------------------
+def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Optional[Mask] = None,
+             out_stats=None):
+    _dev(x, wp, bias, out_stats)
+    assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
+    y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
+    gc = g.c()
+    _check(lib().mopoe_conv_fwd(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), _bn(bn_in), _mask(mask),
+                                _p(out_stats), _stream()))
+    return y
+
+
+def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums=None):
+    _dev(dy, wp, xin, bwd_sums)
+    assert tuple(dy.shape) == g.out_shape
+    dx = torch.empty(g.in_shape, dtype=torch.float32, device=dy.device)
+    gc = g.c()
+    _check(lib().mopoe_conv_dgrad(_p(dy), _p(wp), _p(dx), C.byref(gc), _bn(relu_bn), _p(xin), _p(bwd_sums),
+                                  _stream()))
+    return dx
+
+
+def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None):
+    _dev(x, dy)
+    assert tuple(x.shape) == g.in_shape and tuple(dy.shape) == g.out_shape
+    dwp = torch.empty((g.taps, g.Cin, g.Cout), dtype=torch.float32, device=x.device)
+    gc = g.c()
+    _check(lib().mopoe_conv_wgrad(_p(x), _p(dy), _p(dwp), C.byref(gc), _bn(bn_in), _stream()))
+    return dwp
+
+
+# ----------------------------------------------------------------------------------------------
+# residual-block glue
+# ----------------------------------------------------------------------------------------------
+def _rows(t):
+    return t.numel() // t.shape[-1]
+
+
+def block_out_fwd(s, m, bn_s: Bn, a=RES_A, b=RES_B, out_stats=None):
+    _dev(s, m, out_stats)
+    out = torch.empty_like(s)
+    _check(lib().mopoe_block_out_fwd(_p(s), _p(m), _p(out), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s),
+                                     C.c_float(a), C.c_float(b), _p(out_stats), _stream()))
+    return out
+
+
+def bn_bwd_reduce(g, s, bn_s: Bn):
+    _dev(g, s)
+    sums = new_stats(s.shape[-1], s.device)
+    _check(lib().mopoe_bn_bwd_reduce(_p(g), _p(s), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s), _p(sums),
+                                     _stream()))
+    return sums
+
+
+def block_out_bwd(g, s, bn_s: Bn, sums, mask: Optional[Mask], a=RES_A, b=RES_B, want_colsum_dm=False,
+                  want_colsum_ds=True):
+    """-> dm, ds, dgamma_s, dbeta_s, colsum_dm (or None), colsum_ds (or None)"""
+    _dev(g, s, sums)
+    c = s.shape[-1]
+    dm, ds = torch.empty_like(g), torch.empty_like(g)
+    small = torch.zeros(4, c, dtype=torch.float32, device=g.device)
+    cdm = small[2] if want_colsum_dm else None
+    cds = small[3] if want_colsum_ds else None
+    _check(lib().mopoe_block_out_bwd(_p(g), _p(s), _p(dm), _p(ds), C.c_int64(_rows(s)), c, _bn(bn_s),
+                                     _p(sums), _mask(mask), C.c_float(a), C.c_float(b), _p(small[0]),
+                                     _p(small[1]), _p(cdm), _p(cds), _stream()))
+    return dm, ds, small[0], small[1], cdm, cds
+
+
+def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, want_colsum=False):
+    """-> dx, dgamma, dbeta, colsum_dx (or None)"""
+    _dev(dy, x, sums, add)
+    c = x.shape[-1]
+    dx = torch.empty_like(x)
+    small = torch.zeros(3, c, dtype=torch.float32, device=x.device)
+    cs = small[2] if want_colsum else None
+    _check(lib().mopoe_bn_bwd_apply(_p(dy), _p(x), _p(add), _p(dx), C.c_int64(_rows(x)), c, _bn(bn), _p(sums),
+                                    _mask(mask), _p(small[0]), _p(small[1]), _p(cs), _stream()))
+    return dx, small[0], small[1], cs
+
+
+def bn_running_update(entries: Sequence, momentum=0.1):
+    """entries: iterable of (sums double[2,C], running_mean, running_var, count)."""
+    entries = list(entries)
+    if not entries:
+        return
+    arr = (_RunDesc * len(entries))()
+    for i, (sums, rm, rv, count) in enumerate(entries):
+        _dev(sums, rm, rv)
+        arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
+    raw = bytes(arr)
+    desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(entries[0][1].device, non_blocking=False)
+    _check(lib().mopoe_bn_running_update(_p(desc), len(entries), C.c_float(momentum), _stream()))
+    return desc  # keep alive until the stream has consumed it
+
+
+def colsum(x):
+    _dev(x)
+    out = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device)
+    _check(lib().mopoe_colsum(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# latent space
+# ----------------------------------------------------------------------------------------------
+def _ptr3(ts):
+    arr = (C.c_void_p * 3)()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+_kl_ws = {}
+
+
+def _ws(device, n=8):
+    key = (device.type, device.index, n)
+    if key not in _kl_ws:
+        _kl_ws[key] = torch.zeros(n, dtype=torch.float64, device=device)
+    return _kl_ws[key]
+
+
+def latent_fwd(mu_in, lv_in, eps, row_start, w, norm):
+    """mu_in/lv_in: 3-lists (PA, Lateral, text) of [B,D] or None.
+    -> mus [K,B,D], lvs [K,B,D], joint_mu, joint_lv, z, klds [K], joint_div [1]"""
+    present = [t for t in mu_in if t is not None]
+    _dev(*present, *[t for t in lv_in if t is not None], eps)
+    b, d = present[0].shape
+    k = len(row_start) - 1
+    dev = present[0].device
+    mus = torch.empty(k, b, d, dtype=torch.float32, device=dev)
+    lvs = torch.empty_like(mus)
+    jm, jl, z = (torch.empty(b, d, dtype=torch.float32, device=dev) for _ in range(3))
+    klds = torch.empty(k, dtype=torch.float32, device=dev)
+    jd = torch.empty(1, dtype=torch.float32, device=dev)
+    rs = (C.c_int32 * (k + 1))(*row_start)
+    wa = (C.c_float * k)(*w)
+    _check(lib().mopoe_latent_fwd(_ptr3(mu_in), _ptr3(lv_in), _p(eps), b, d, rs, wa, C.c_float(norm), _p(mus),
+                                  _p(lvs), _p(jm), _p(jl), _p(z), _p(klds), _p(jd), _p(_ws(dev)),
+                                  _stream()))
+    return mus, lvs, jm, jl, z, klds, jd
+
+
+def latent_bwd(mu_in, lv_in, eps, row_start, w, norm, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd):
+    """-> (d_mu_in[3], d_lv_in[3]) with None for absent modalities."""
+    present = [t for t in mu_in if t is not None]
+    _dev(*present, eps, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd)
+    b, d = present[0].shape
+    dmu = [None if t is None else torch.empty_like(t) for t in mu_in]
+    dlv = [None if t is None else torch.empty_like(t) for t in lv_in]
+    k = len(row_start) - 1
+    rs = (C.c_int32 * (k + 1))(*row_start)
+    wa = (C.c_float * k)(*w)
+    _check(lib().mopoe_latent_bwd(_ptr3(mu_in), _ptr3(lv_in), _p(eps), b, d, rs, wa, C.c_float(norm), _p(g_mus),
+                                  _p(g_lvs), _p(g_jm), _p(g_jl), _p(g_z), _p(g_klds), _p(g_jd), _ptr3(dmu),
+                                  _ptr3(dlv), _stream()))
+    return dmu, dlv
+
+
+# ----------------------------------------------------------------------------------------------
+# likelihoods, embedding
+# ----------------------------------------------------------------------------------------------
+def laplace_nll_fwd(x_hat, x, scale, norm):
+    _dev(x_hat, x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _check(lib().mopoe_laplace_nll_fwd(_p(x_hat), _p(x), C.c_int64(x.numel()), C.c_float(scale), C.c_float(norm),
+                                       _p(out), _p(_ws(x.device)), _stream()))
+    return out
+
+
+def laplace_nll_bwd(x_hat, x, g, scale, norm):
+    _dev(x_hat, x, g)
+    dx = torch.empty_like(x_hat)
+    _check(lib().mopoe_laplace_nll_bwd(_p(x_hat), _p(x), _p(g), C.c_int64(x.numel()), C.c_float(scale),
+                                       C.c_float(norm), _p(dx), _stream()))
+    return dx
+
+
+def logsoftmax_fwd(x, inplace=False):
+    _dev(x)
+    y = x if inplace else torch.empty_like(x)
+    _check(lib().mopoe_logsoftmax_fwd(_p(x), _p(y), C.c_int64(_rows(x)), x.shape[-1], _stream()))
+    return y
+
+
+def logsoftmax_bwd(dy, y, inplace=False):
+    _dev(dy, y)
+    dx = dy if inplace else torch.empty_like(dy)
+    _check(lib().mopoe_logsoftmax_bwd(_p(dy), _p(y), _p(dx), C.c_int64(_rows(y)), y.shape[-1], _stream()))
+    return dx
+
+
+def token_nll_fwd(logp, ids, norm):
+    _dev(logp, ids)
+    out = torch.empty(1, dtype=torch.float32, device=logp.device)
+    _check(lib().mopoe_token_nll_fwd(_p(logp), _p(ids), C.c_int64(ids.numel()), logp.shape[-1], C.c_float(norm),
+                                     _p(out), _p(_ws(logp.device)), _stream()))
+    return out
+
+
+def token_nll_bwd(ids, g, shape, norm):
+    _dev(ids, g)
+    dlogp = torch.empty(shape, dtype=torch.float32, device=ids.device)
+    _check(lib().mopoe_token_nll_bwd(_p(ids), _p(g), C.c_int64(ids.numel()), shape[-1], C.c_float(norm),
+                                     _p(dlogp), _stream()))
+    return dlogp
+
+
+def embedding_fwd(ids, table):
+    _dev(ids, table)
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    _check(lib().mopoe_embedding_fwd(_p(ids), _p(table), _p(out), C.c_int64(ids.numel()), table.shape[0],
+                                     table.shape[1], _stream()))
+    return out
+
+
+def embedding_bwd(ids, gout, vocab, padding_idx=0):
+    _dev(ids, gout)
+    dtable = torch.empty(vocab, gout.shape[-1], dtype=torch.float32, device=gout.device)
+    _check(lib().mopoe_embedding_bwd(_p(ids), _p(gout), _p(dtable), C.c_int64(ids.numel()), vocab, gout.shape[-1],
+                                     padding_idx, _stream()))
+    return dtable
+
+
+# ----------------------------------------------------------------------------------------------
+# profiling hooks used by bench.py
+# ----------------------------------------------------------------------------------------------
+def prof_enable(on: bool):
+    _check(lib().mopoe_prof_enable(int(on)))
+
+
+def prof_collect():
+    n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+    _check(lib().mopoe_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)))
+    return n.value, ms.value, fl.value

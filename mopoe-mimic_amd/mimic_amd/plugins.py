@@ -1,0 +1,181 @@
+"""Modality plugin API and the fused likelihood objects.
+
+Keeps the reference's Modality contract (mimic/modalities/Modality.py:15-47, MimicPA.py:7-17,
+MimicLateral.py:7-17, MimicText.py:12-40, modalities/utils.py:4-15): a modality carries ``name``,
+``likelihood_name``, ``data_size``, ``gen_quality_eval``, ``file_suffix``, ``encoder``, ``decoder``,
+``likelihood`` and ``calc_log_prob(out_dist, target, norm_value)``.  ``likelihood`` constructs an
+object with ``.log_prob(target)`` and ``.mean`` like the torch.distributions classes the reference
+uses, plus a fused path: summed log-probability in one HIP reduction (no [B,L,V] one-hot, no
+elementwise log_prob tensor).
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import ops
+
+
+# ---- fused likelihoods -------------------------------------------------------------------------
+class _LaplaceNll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, target, scale, norm):
+        loc_c, tgt = loc.contiguous(), target.contiguous()
+        ctx.save_for_backward(loc_c, tgt)
+        ctx.scale, ctx.norm = scale, norm
+        return ops.laplace_nll_fwd(loc_c, tgt, scale, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, tgt = ctx.saved_tensors
+        return ops.laplace_nll_bwd(loc, tgt, g.contiguous(), ctx.scale, ctx.norm), None, None, None
+
+
+class _TokenNll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, ids, norm):
+        ids_c = ids.contiguous()
+        ctx.save_for_backward(ids_c)
+        ctx.shape, ctx.norm = tuple(logp.shape), norm
+        return ops.token_nll_fwd(logp.contiguous(), ids_c, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        return ops.token_nll_bwd(ids, g.contiguous(), ctx.shape, ctx.norm), None, None
+
+
+class FusedLaplace:
+    """Stand-in for torch.distributions.Laplace(loc, scale) as the image decoders' output."""
+
+    def __init__(self, loc, scale):
+        self.loc = loc
+        const = getattr(scale, "_mopoe_const", None)
+        self.scale_value = float(scale) if const is None else const
+        self.scale = scale
+
+    @property
+    def mean(self):
+        return self.loc
+
+    def log_prob(self, value):  # elementwise; evaluation-only path (torch on device)
+        return -math.log(2 * self.scale_value) - torch.abs(value - self.loc) / self.scale_value
+
+    def summed_log_prob(self, target, norm_value):
+        """sum(log_prob(target)) / norm_value as one HIP reduction (0-dim tensor)."""
+        return -_LaplaceNll.apply(self.loc, target, self.scale_value, float(norm_value)).view(())
+
+
+class FusedOneHotCategorical:
+    """Stand-in for torch.distributions.OneHotCategorical(logits=log-probabilities [B,L,V])."""
+
+    def __init__(self, probs=None, logits=None):
+        if logits is None:
+            raise NotImplementedError("construct with logits= (the text decoder emits log-probabilities)")
+        self.logits = logits
+
+    @property
+    def probs(self):
+        return torch.exp(self.logits)
+
+    @property
+    def mean(self):
+        return self.probs
+
+    def log_prob(self, value):  # value: one-hot [B,L,V]; evaluation-only path
+        return (value * self.logits).sum(-1)
+
+    def summed_log_prob(self, target_ids, norm_value):
+        """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised)."""
+        return -_TokenNll.apply(self.logits, target_ids, float(norm_value)).view(())
+
+
+def get_likelihood(name: str):
+    if name == "laplace":
+        return FusedLaplace
+    if name == "categorical":
+        return FusedOneHotCategorical
+    if name in ("bernoulli", "normal"):
+        raise NotImplementedError(f"likelihood '{name}' is never selected by the MIMIC modalities "
+                                  "(SURVEY §0) and has no HIP path")
+    print("likelihood not implemented")
+    return None
+
+
+# ---- modalities --------------------------------------------------------------------------------
+class Modality(ABC):
+    @abstractmethod
+    def save_data(self, exp, d, fn, args):
+        ...
+
+    @abstractmethod
+    def plot_data(self, exp, d):
+        ...
+
+    def calc_log_prob(self, out_dist, target: torch.Tensor, norm_value: int):
+        """log P(target | out_dist) summed over everything, divided by norm_value."""
+        if hasattr(out_dist, "summed_log_prob"):
+            return out_dist.summed_log_prob(target, norm_value)
+        return out_dist.log_prob(target).sum() / norm_value
+
+
+class ModalityIMG(Modality):
+    def __init__(self, data_size):
+        self.data_size = data_size
+
+    def save_data(self, exp, d, fn, args):
+        raise NotImplementedError("sample dumps are outside the training hot path (SURVEY §2.1-17)")
+
+    def plot_data(self, exp, d, log_tag=None):
+        raise NotImplementedError("plotting is outside the training hot path (SURVEY §2.1-17)")
+
+
+class _MimicImage(ModalityIMG):
+    def __init__(self, name, enc, dec, args):
+        self.name = name
+        self.likelihood_name = "laplace"
+        super().__init__(torch.Size((1, args.img_size, args.img_size)))
+        self.gen_quality_eval = True
+        self.file_suffix = ".png"
+        self.encoder, self.decoder = enc, dec
+        self.likelihood = get_likelihood(self.likelihood_name)
+
+
+class MimicPA(_MimicImage):
+    def __init__(self, enc, dec, args):
+        super().__init__("PA", enc, dec, args)
+
+
+class MimicLateral(_MimicImage):
+    def __init__(self, enc, dec, args):
+        super().__init__("Lateral", enc, dec, args)
+
+
+class MimicText(Modality):
+    def __init__(self, enc, dec, len_sequence, plotImgSize, font, args):
+        if args.text_encoding != "word":
+            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
+        self.name = "text"
+        self.args = args
+        self.likelihood_name = "categorical"
+        self.len_sequence = len_sequence
+        self.data_size = torch.Size((args.vocab_size, len_sequence))
+        self.plot_img_size, self.font = plotImgSize, font
+        self.gen_quality_eval = False
+        self.file_suffix = ".txt"
+        self.encoder, self.decoder = enc, dec
+        self.likelihood = get_likelihood(self.likelihood_name)
+
+    def save_data(self, exp, d, fn, args):
+        raise NotImplementedError("sample dumps are outside the training hot path (SURVEY §2.1-17)")
+
+    def plot_data(self, exp, d, log_tag=None):
+        raise NotImplementedError("plotting is outside the training hot path (SURVEY §2.1-17)")
+
+    def calc_log_prob(self, out_dist, target: torch.Tensor, norm_value: int):
+        if hasattr(out_dist, "summed_log_prob") and target.dim() == out_dist.logits.dim() - 1:
+            return out_dist.summed_log_prob(target, norm_value)  # float ids, as the data loader yields them
+        onehot = torch.nn.functional.one_hot(target.to(torch.int64), num_classes=self.args.vocab_size)
+        return out_dist.log_prob(onehot).sum() / norm_value

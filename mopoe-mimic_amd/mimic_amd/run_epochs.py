@@ -1,0 +1,180 @@
+"""Epoch driver for the hot path: same function names and per-step contract as the reference's
+mimic/run_epochs.py (set_random_seed :31-34, basic_routine_epoch :52-96, train :99-145, test :148-183,
+run_epochs :231-272), re-designed around the device:
+
+  * one forward = 6 network nodes + 1 fused latent node + 3 likelihood reductions (no Python loop over
+    subsets, no device->host sync inside the step: the reference has 21 `.item()`/`.cpu()` per step);
+  * the 18 logged scalars (loss, 7 KL, 3 NLL, joint divergence, 3 x (mean mu, mean logvar)) are packed
+    on the device and read back with ONE asynchronous copy per step;
+  * data parallelism = one process per GPU, gradients averaged with RCCL all-reduce on flat buckets
+    (mimic_amd.parallel), the scalar pack summed across ranks in the same step.
+"""
+from __future__ import annotations
+
+import random
+import typing
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+from .evaluation.losses import calc_joint_elbo_loss, calc_klds, calc_log_probs
+from .parallel import GradAllReducer
+from .utils.exceptions import CudaOutOfMemory, NaNInLatent
+
+SCALAR_NAMES_FIXED = ["total_loss", "joint_divergence"]
+
+
+def set_random_seed(seed: int):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    random.seed(seed)
+
+
+@contextmanager
+def catching_cuda_out_of_memory(batch_size):
+    """The reference matches 'CUDA out of memory.'; on ROCm the allocator says 'HIP out of memory.'
+    (SURVEY §5): both are translated so the caller's retry-with-smaller-batch contract holds."""
+    try:
+        yield
+    except RuntimeError as e:
+        msg = str(e)
+        if (msg.startswith("CUDA out of memory.") or msg.startswith("HIP out of memory.")
+                or isinstance(e, torch.cuda.OutOfMemoryError)) and batch_size > 10:
+            raise CudaOutOfMemory(e)
+        raise
+
+
+def basic_routine_epoch(exp, batch) -> typing.Mapping[str, any]:
+    flags = exp.flags
+    batch_d = batch[0]
+    for m_key in batch_d.keys():
+        batch_d[m_key] = batch_d[m_key].to(flags.device, non_blocking=True)
+    with catching_cuda_out_of_memory(batch_size=flags.batch_size):
+        results = exp.mm_vae(batch_d)
+        log_probs, weighted_log_prob = calc_log_probs(exp, results, batch)
+    group_divergence = results["joint_divergence"]
+    klds = calc_klds(exp, results)
+    total_loss = calc_joint_elbo_loss(exp, None, group_divergence, flags.beta_style, flags.beta_content,
+                                      weighted_log_prob, flags.beta)
+    return {"results": results, "log_probs": log_probs, "total_loss": total_loss, "klds": klds}
+
+
+class ScalarPack:
+    """Device-side pack of the per-step logging scalars + one async D2H copy into pinned memory."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = None
+        self.names: typing.List[str] = []
+        self.event = None
+
+    def submit(self, routine, reducer: typing.Optional["GradAllReducer"] = None):
+        res = routine["results"]
+        names, vals = ["total_loss", "joint_divergence"], [routine["total_loss"].detach().reshape(1),
+                                                           res["joint_divergence"].detach().reshape(1)]
+        for k, v in routine["klds"].items():
+            names.append("klds/" + k)
+            vals.append(v.detach().reshape(1))
+        for k, v in routine["log_probs"].items():
+            names.append("log_probs/" + k)
+            vals.append(v.detach().reshape(1))
+        for k, (mu, lv) in res["latents"]["modalities"].items():
+            if mu is None:
+                continue
+            names += [f"latents/{k}/mu", f"latents/{k}/logvar"]
+            vals += [mu.detach().mean().reshape(1), lv.detach().mean().reshape(1)]
+        packed = torch.cat(vals)
+        if reducer is not None and reducer.world_size > 1:
+            packed = reducer.mean_scalars(packed)
+        if self.host is None or self.host.numel() != packed.numel():
+            self.host = torch.empty(packed.numel(), dtype=torch.float32,
+                                    pin_memory=(self.device.type == "cuda"))
+        self.host.copy_(packed, non_blocking=True)
+        self.names = names
+        if self.device.type == "cuda":
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def read(self) -> typing.Dict[str, float]:
+        if self.event is not None:
+            self.event.synchronize()
+        return dict(zip(self.names, self.host.tolist()))
+
+
+def train_step(exp, batch, reducer=None, pack: typing.Optional[ScalarPack] = None):
+    """One optimiser step of run_epochs.train (:122-131)."""
+    routine = basic_routine_epoch(exp, batch)
+    exp.optimizer.zero_grad(set_to_none=True)
+    with catching_cuda_out_of_memory(exp.flags.batch_size):
+        routine["total_loss"].backward()
+    if reducer is not None:
+        reducer.all_reduce_grads()
+    exp.optimizer.step()
+    if pack is not None:
+        pack.submit(routine, reducer)
+    return routine
+
+
+def train(exp, train_loader, reducer=None, max_steps=None):
+    """Returns the last step's scalars, like the reference's meters do (AverageMeter.get_average
+    returns the last value, average_meters.py:33-34) plus running means of the dict-valued meters."""
+    exp.mm_vae.train()
+    pack = ScalarPack(exp.flags.device)
+    sums, n, last = {}, 0, {}
+    steps = exp.flags.steps_per_training_epoch if 0 < exp.flags.steps_per_training_epoch else max_steps
+    for it, batch in enumerate(train_loader):
+        if steps and it >= steps:
+            break
+        if n:  # read the PREVIOUS step's scalars while this step is being enqueued
+            last = pack.read()
+            _check_nan(exp, last)
+            for k, v in last.items():
+                sums[k] = sums.get(k, 0.0) + v
+        train_step(exp, batch, reducer, pack)
+        n += 1
+    if n:
+        last = pack.read()
+        _check_nan(exp, last)
+        for k, v in last.items():
+            sums[k] = sums.get(k, 0.0) + v
+    means = {k: v / max(n, 1) for k, v in sums.items()}
+    return {"last": last, "mean": means, "steps": n}
+
+
+def _check_nan(exp, scalars):
+    if getattr(exp.flags, "dataset", None) == "testing":
+        return
+    for k, v in scalars.items():
+        if k.startswith("latents/") and v != v:
+            raise NaNInLatent(k)
+
+
+def test(epoch, exp, test_loader, max_steps=None):
+    """no-grad pass with BatchNorm running statistics (run_epochs.test :148-183, logging only)."""
+    exp.mm_vae.eval()
+    pack = ScalarPack(exp.flags.device)
+    out, n = {}, 0
+    with torch.no_grad():
+        for it, batch in enumerate(test_loader):
+            if max_steps and it >= max_steps:
+                break
+            routine = basic_routine_epoch(exp, batch)
+            pack.submit(routine)
+            for k, v in pack.read().items():
+                out[k] = out.get(k, 0.0) + v
+            n += 1
+    return {k: v / max(n, 1) for k, v in out.items()}
+
+
+def run_epochs(rank, exp, train_loader_fn, epochs: int, world_size: int = 1):
+    """One process per GPU.  ``train_loader_fn(rank, world_size)`` yields ((dict, labels)) batches."""
+    set_random_seed(exp.flags.seed)
+    exp.set_optimizer()
+    reducer = GradAllReducer(exp.mm_vae, world_size) if world_size > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters()
+    history = []
+    for epoch in range(epochs):
+        history.append(train(exp, train_loader_fn(rank, world_size), reducer))
+    return history

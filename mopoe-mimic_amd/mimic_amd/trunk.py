@@ -1,0 +1,162 @@
+"""Residual trunks: the forward and the hand-written backward of a chain of residual blocks,
+expressed as launches of the HIP ops (mimic_amd.ops).  One chain serves all four networks
+(2-D conv encoder, 2-D transposed-conv decoder, 1-D conv text encoder, 1-D transposed text decoder).
+
+Reference semantics (mimic/networks/ResidualBlocks.py:20-33,51-65,84-97,118-131):
+    main(x)  = drop2(conv2(relu(bn2(drop1(conv1(relu(bn1(x))))))))
+    out      = 2.0 * BN_s(conv_s(x)) + 0.3 * main(x)
+What is materialised per block in HBM: d1 = drop1(conv1(.)), m = drop2(conv2(.)), s = conv_s(x), out.
+BN -> ReLU is applied while the next conv loads its operand; BN statistics are accumulated by the
+epilogue of the kernel that produces the tensor.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .layout import ResBlockParams
+from .ops import Bn, Geom, Mask
+
+
+@dataclass
+class BlockSpec:
+    params: ResBlockParams
+    g1: Geom          # 1x1 conv on the block's input grid
+    g2: Geom          # k4 conv (main conv2 and shortcut share it)
+    twod: bool        # Dropout2d (channel masks) vs Dropout (elementwise)
+    name: str         # e.g. 'feature_extractor.resblock_1.0'
+
+
+class MaskSource:
+    """Where dropout masks come from.  Default: drawn with torch on the tensors' device (p = 0.5,
+    multiplier 2), in the reference's order.  Tests install a replay source (masks captured from the
+    reference run, reference layout [N,C,1,1] / [N,C,L])."""
+
+    def __init__(self, replay: Optional[Dict[str, torch.Tensor]] = None, prefix: str = ""):
+        self.replay, self.prefix = replay, prefix
+
+    def get(self, name: str, n: int, rows_per_sample: int, c: int, twod: bool, device) -> Mask:
+        if self.replay is not None:
+            m = self.replay[self.prefix + name].to(device=device, dtype=torch.float32)
+            if twod:
+                return Mask(m.reshape(n, c).contiguous(), 1, rows_per_sample)
+            return Mask(m.reshape(n, c, rows_per_sample).permute(0, 2, 1).contiguous(), 2, rows_per_sample)
+        if twod:
+            m = (torch.rand(n, c, device=device) < 0.5).to(torch.float32).mul_(2.0)
+            return Mask(m, 1, rows_per_sample)
+        m = (torch.rand(n, rows_per_sample, c, device=device) < 0.5).to(torch.float32).mul_(2.0)
+        return Mask(m, 2, rows_per_sample)
+
+
+def _bn(p, training: bool, sums, count) -> Bn:
+    if training:
+        return Bn(p.weight, p.bias, 1, sums=sums, count=count)
+    return Bn(p.weight, p.bias, 2, rmean=p.running_mean, rvar=p.running_var)
+
+
+def stats_needed(blocks: List[BlockSpec]) -> int:
+    """number of double elements the trunk's BN statistics need (stem output + per block d1, s, out)"""
+    n = 2 * blocks[0].g1.Cin
+    for b in blocks:
+        n += 2 * (b.g1.Cin + 2 * b.g2.Cout)
+    return n
+
+
+class StatsArena:
+    """One zero-filled double buffer per network forward, handed out in [2, C] slices."""
+
+    def __init__(self, n_doubles: int, device, enabled: bool):
+        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=device) if enabled else None
+        self.off = 0
+
+    def take(self, c: int):
+        if self.buf is None:
+            return None
+        v = self.buf[self.off:self.off + 2 * c].view(2, c)
+        self.off += 2 * c
+        return v
+
+
+def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: bool, masks: MaskSource,
+                  arena: StatsArena, batch: int):
+    """x: [N,H,W,C] output of the stem, x_stats: its column statistics (train) or None (eval).
+    Returns (out, saved) where saved is the per-block state the backward needs."""
+    saved = []
+    running = []
+    for spec in blocks:
+        p, g1, g2 = spec.params, spec.g1.with_batch(batch), spec.g2.with_batch(batch)
+        rows_in = x.numel() // x.shape[-1]
+        rps_in = rows_in // batch
+        bn1 = _bn(p.bn1, training, x_stats, rows_in)
+        if training:
+            running.append((x_stats, p.bn1, rows_in))
+        mask1 = mask2 = None
+        if dropout:
+            mask1 = masks.get(spec.name + ".dropout1", batch, rps_in, g1.Cout, spec.twod, x.device)
+        st_d1 = arena.take(g1.Cout)
+        d1 = ops.conv_fwd(x, p.conv1.weight, g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
+        bn2 = _bn(p.bn2, training, st_d1, rows_in)
+        if training:
+            running.append((st_d1, p.bn2, rows_in))
+        rows_out = batch * (g2.Hb * g2.Wb if g2.transposed else g2.Hs * g2.Ws)
+        rps_out = rows_out // batch
+        if dropout:
+            mask2 = masks.get(spec.name + ".dropout2", batch, rps_out, g2.Cout, spec.twod, x.device)
+        m = ops.conv_fwd(d1, p.conv2.weight, g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
+        st_s = arena.take(g2.Cout)
+        sconv, sbn = p.short[0], p.short[1]
+        s = ops.conv_fwd(x, sconv.weight, g2, bias=sconv.bias, out_stats=st_s)
+        bns = _bn(sbn, training, st_s, rows_out)
+        if training:
+            running.append((st_s, sbn, rows_out))
+        st_out = arena.take(g2.Cout)
+        out = ops.block_out_fwd(s, m, bns, out_stats=st_out)
+        saved.append(dict(x=x, d1=d1, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2))
+        x, x_stats = out, st_out
+    return x, saved, running
+
+
+def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor]):
+    """g: gradient w.r.t. the trunk output.  Fills ``grads`` (keyed by parameter name relative to the
+    network) and returns the gradient w.r.t. the trunk input."""
+    for spec, sv in zip(reversed(blocks), reversed(saved)):
+        p, g1, g2 = spec.params, sv["g1"], sv["g2"]
+        x, d1, s = sv["x"], sv["d1"], sv["s"]
+        bn1, bn2, bns = sv["bn1"], sv["bn2"], sv["bns"]
+        has_bias = p.conv1.bias is not None
+        n = spec.name
+        sums_s = ops.bn_bwd_reduce(g, s, bns)
+        dm, ds, dgs, dbs, cdm, cds = ops.block_out_bwd(g, s, bns, sums_s, sv["mask2"],
+                                                       want_colsum_dm=has_bias, want_colsum_ds=True)
+        sums2 = ops.new_stats(g1.Cout, g.device)
+        dh2 = ops.conv_dgrad(dm, p.conv2.weight, g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
+        grads[f"{n}.conv2.weight"] = ops.conv_wgrad(d1, dm, g2, bn_in=bn2)
+        dxs = ops.conv_dgrad(ds, p.short[0].weight, g2)
+        grads[f"{n}.{p.short_name}.0.weight"] = ops.conv_wgrad(x, ds, g2)
+        grads[f"{n}.{p.short_name}.0.bias"] = cds
+        grads[f"{n}.{p.short_name}.1.weight"] = dgs
+        grads[f"{n}.{p.short_name}.1.bias"] = dbs
+        dc1, dg2, db2, cdc1 = ops.bn_bwd_apply(dh2, d1, bn2, sums2, mask=sv["mask1"], want_colsum=has_bias)
+        grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
+        sums1 = ops.new_stats(g1.Cin, g.device)
+        dh1 = ops.conv_dgrad(dc1, p.conv1.weight, g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
+        grads[f"{n}.conv1.weight"] = ops.conv_wgrad(x, dc1, g1, bn_in=bn1)
+        if has_bias:
+            grads[f"{n}.conv2.bias"] = cdm
+            grads[f"{n}.conv1.bias"] = cdc1
+        g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs)
+        grads[f"{n}.bn1.weight"], grads[f"{n}.bn1.bias"] = dg1, db1
+    return g
+
+
+def apply_running_updates(running, momentum=0.1):
+    """BatchNorm train-mode side effect for every BN of a network, one launch."""
+    if not running:
+        return
+    ops.bn_running_update([(sums, bn.running_mean, bn.running_var, count) for sums, bn, count in running],
+                          momentum)
+    for _, bn, _ in running:
+        bn.pending_batches += 1  # flushed into num_batches_tracked when state_dict() is taken

@@ -1,0 +1,78 @@
+"""Hot-path subset of the reference's MimicExperiment (mimic/utils/experiment.py:41-92,171-190,
+BaseExperiment.py:66-82): modalities, subsets, model, optimizer, reconstruction weights.  Datasets,
+classifiers, CSV bookkeeping, fonts and plotting are outside the training step."""
+from __future__ import annotations
+
+import argparse
+from itertools import chain, combinations
+
+import torch
+import torch.optim as optim
+
+from ..nets import DecoderImg, DecoderText, EncoderImg, EncoderText
+from ..mmvae import VAEtrimodalMimic
+from ..plugins import MimicLateral, MimicPA, MimicText
+
+
+def default_flags(**overrides) -> argparse.Namespace:
+    """The flag fields the hot path reads, with the reference's defaults / cluster-config values
+    (mimic/utils/flags.py:23-114, BaseFlags.py:4-113, configs/leomed_mimic_config.json)."""
+    f = argparse.Namespace(
+        img_size=128, image_channels=1, DIM_img=64, DIM_text=128, class_dim=128, batch_size=64,
+        style_pa_dim=0, style_lat_dim=0, style_text_dim=0, text_encoding="word", len_sequence=128,
+        vocab_size=3517, text_gen_lastlayer="softmax", feature_extractor_img="resnet",
+        factorized_representation=False, method="joint_elbo", modality_poe=False, modality_moe=False,
+        modality_jsd=False, joint_elbo=True, poe_unimodal_elbos=False, only_text_modality=False,
+        beta=1.0, beta_style=1.0, beta_content=1.0, beta_m1_style=1.0, beta_m2_style=1.0, beta_m3_style=1.0,
+        div_weight_uniform_content=0.25, div_weight_m1_content=0.25, div_weight_m2_content=0.25,
+        div_weight_m3_content=0.25, rec_weight_m1=0.33, rec_weight_m2=0.33, rec_weight_m3=0.33,
+        initial_learning_rate=5e-4, beta_1=0.9, beta_2=0.999, dataset="testing", distributed=False,
+        steps_per_training_epoch=0, seed=0, device=torch.device("cuda" if torch.cuda.is_available() else "cpu"),
+        encoder_save_m1="encoderM1", encoder_save_m2="encoderM2", encoder_save_m3="encoderM3",
+        decoder_save_m1="decoderM1", decoder_save_m2="decoderM2", decoder_save_m3="decoderM3",
+        dir_checkpoints=".")
+    f.__dict__.update(overrides)
+    f.alpha_modalities = [f.div_weight_uniform_content, f.div_weight_m1_content, f.div_weight_m2_content,
+                          f.div_weight_m3_content]
+    return f
+
+
+class HotPathExperiment:
+    """Carries exactly what run_epochs.basic_routine_epoch / train read from the experiment object."""
+
+    def __init__(self, flags):
+        self.flags = flags
+        self.dataset = flags.dataset
+        self.modalities = self.set_modalities()
+        self.num_modalities = len(self.modalities)
+        self.subsets = self.set_subsets()
+        self.mm_vae = self.set_model()
+        self.optimizer = None
+        self.rec_weights = self.set_rec_weights()
+        self.style_weights = {"PA": flags.beta_m1_style, "Lateral": flags.beta_m2_style, "text": flags.beta_m3_style}
+
+    def set_modalities(self):
+        f = self.flags
+        mod1 = MimicPA(EncoderImg(f, f.style_pa_dim), DecoderImg(f, f.style_pa_dim), f)
+        mod2 = MimicLateral(EncoderImg(f, f.style_lat_dim), DecoderImg(f, f.style_lat_dim), f)
+        mod3 = MimicText(EncoderText(f, f.style_text_dim), DecoderText(f, f.style_text_dim), f.len_sequence,
+                         None, None, f)
+        return {mod1.name: mod1, mod2.name: mod2, mod3.name: mod3}
+
+    def set_subsets(self):
+        xs = list(self.modalities)
+        subsets = {}
+        for names in chain.from_iterable(combinations(xs, n) for n in range(len(xs) + 1)):
+            subsets["_".join(sorted(names))] = [self.modalities[m] for m in sorted(names)]
+        return subsets
+
+    def set_model(self):
+        return VAEtrimodalMimic(self.flags, self.modalities, self.subsets)
+
+    def set_optimizer(self):
+        self.optimizer = optim.Adam(list(self.mm_vae.parameters()), lr=self.flags.initial_learning_rate,
+                                    betas=(self.flags.beta_1, self.flags.beta_2))
+
+    def set_rec_weights(self):
+        f = self.flags
+        return {"PA": f.rec_weight_m1, "Lateral": f.rec_weight_m2, "text": f.rec_weight_m3}

@@ -105,13 +105,16 @@ def build_reference(cfg: R.Cfg, sd):
 class Capture:
     """Captures eps (by wrapping utils.reparameterize) and dropout masks (forward hooks)."""
 
-    def __init__(self, model):
+    def __init__(self, model, force_eps=None):
         import mimic.utils.utils as U
         self.U, self.orig = U, U.reparameterize
         self.eps, self.masks, self.hooks = None, {}, []
         cap = self
 
         def wrapped(mu, logvar):
+            if force_eps is not None:
+                cap.eps = force_eps
+                return force_eps.to(mu.dtype) * torch.exp(0.5 * logvar) + mu
             z = cap.orig(mu, logvar)
             cap.eps = ((z - mu) / torch.exp(0.5 * logvar)).detach()
             return z
@@ -143,7 +146,7 @@ class Capture:
             h.remove()
 
 
-def run_reference(run_epochs, exp, batch, mode, seed=1234):
+def run_reference(run_epochs, exp, batch, mode, seed=1234, force_eps=None):
     model = exp.mm_vae
     if mode == "eval":
         model.eval()
@@ -154,7 +157,7 @@ def run_reference(run_epochs, exp, batch, mode, seed=1234):
                 if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
                     m.eval()
     model.zero_grad()
-    cap = Capture(model)
+    cap = Capture(model, force_eps)
     torch.manual_seed(seed)
     b = ({k: v.clone() for k, v in batch.items()}, None)
     out = run_epochs.basic_routine_epoch(exp, b)
@@ -202,36 +205,69 @@ def batch_to_store(batch, store, prefix="in"):
     store[f"{prefix}/text"] = batch["text"].to(torch.int32).numpy()
 
 
-def break_ties(run_epochs, cfg, sd, batch, modes, margin=2e-4, max_iter=20):
+def break_ties(run_epochs, cfg, sd, batch, modes, margin=2e-3, max_iter=40):
     """The Laplace log-likelihood has a discontinuous gradient (sign(x - x_hat)).  A pixel whose
     |x - x_hat| is within fp32 noise flips sign between implementations and moves every upstream
     gradient by ~1e-2 relative, so the fixtures avoid such pixels: any input pixel closer than
     ``margin`` to its reconstruction (in any mode) is bumped by one grey level until none remains."""
+    direction = {m: torch.where(batch[m] < 0.5, 2.0, -2.0) for m in ("PA", "Lateral")}  # fixed per pixel
     for it in range(max_iter):
         n_bad = 0
         for mode in modes:
             exp = build_reference(cfg, sd)
             out, cap = run_reference(run_epochs, exp, batch, mode)
             for m in ("PA", "Lateral"):
-                near = (batch[m] - out["results"]["rec"][m].loc.detach()).abs() < margin
+                diff = batch[m] - out["results"]["rec"][m].loc.detach()
+                near = diff.abs() < margin
                 if near.any():
                     n_bad += int(near.sum())
                     u8 = (batch[m] * 255.0).round()
-                    u8 = torch.where(near, torch.where(u8 < 128, u8 + 1, u8 - 1), u8)
-                    batch[m] = u8 / 255.0
+                    # two grey levels (7.8e-3 > 2*margin), always towards mid-grey: monotone, so the
+                    # three modes' slightly different reconstructions cannot make a pixel oscillate
+                    batch[m] = torch.where(near, u8 + direction[m], u8) / 255.0
+        print(f"  tie-breaking pass {it}: {n_bad} pixels within {margin} of their reconstruction")
         if n_bad == 0:
             return batch
     raise RuntimeError("could not remove Laplace ties")
 
 
+def conditioning(run_epochs, cfg, sd, batch, modes):
+    """Worst normalised deviation between the reference run in fp32 and in fp64 (gradients of every
+    parameter).  Tiny-batch train-mode BatchNorm can be arbitrarily ill-conditioned; fixtures are
+    only kept when fp32 noise of the REFERENCE ITSELF is far below the tolerance the tests use."""
+    worst = 0.0
+    for mode in modes:
+        grads, eps = {}, None
+        for dt in (torch.float32, torch.float64):
+            exp = build_reference(cfg, sd)
+            exp.mm_vae.to(dt)
+            b = {k: v.to(dt) for k, v in batch.items()}
+            _, cap = run_reference(run_epochs, exp, b, mode, force_eps=eps)
+            eps = cap.eps
+            grads[dt] = {n: p.grad.double() for n, p in exp.mm_vae.named_parameters() if p.grad is not None}
+        for n, g64 in grads[torch.float64].items():
+            scale = g64.abs().max().item()
+            if n.endswith(".bias") and n[:-4] + "weight" in grads[torch.float64]:
+                scale = max(scale, grads[torch.float64][n[:-4] + "weight"].abs().max().item())
+            worst = max(worst, (grads[torch.float32][n] - g64).abs().max().item() / max(scale, 1e-3))
+    return worst
+
+
 def gen_g0(run_epochs, size, nrow):
     cfg = R.Cfg(img_size=size, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=nrow)
-    sd = R.init_state(cfg, seed=100 + size)
-    # make the padding row non-zero so that "forward reads row 0, backward skips it" is exercised
-    sd["encoder_text.feature_extractor.embedding.weight"][0] = 0.25
-    batch, _ = R.synthetic_batch(cfg, nrow, seed=size)
-    batch["text"][:, :3] = 0.0  # force some padding tokens
-    batch = break_ties(run_epochs, cfg, sd, batch, ("eval", "train_nodrop", "train"))
+    for attempt in range(30):
+        sd = R.init_state(cfg, seed=100 + size + 1000 * attempt)
+        # make the padding row non-zero so that "forward reads row 0, backward skips it" is exercised
+        sd["encoder_text.feature_extractor.embedding.weight"][0] = 0.25
+        batch, _ = R.synthetic_batch(cfg, nrow, seed=size + 1000 * attempt)
+        batch["text"][:, :3] = 0.0  # force some padding tokens
+        batch = break_ties(run_epochs, cfg, sd, batch, ("eval", "train_nodrop", "train"))
+        cond = conditioning(run_epochs, cfg, sd, batch, ("eval", "train_nodrop"))
+        print(f"g0_s{size} attempt {attempt}: fp32-vs-fp64 deviation of the reference = {cond:.2e}")
+        if cond < 3e-4:
+            break
+    else:
+        raise RuntimeError("no well-conditioned fixture found")
     store = {"cfg": np.array([size, cfg.class_dim, cfg.DIM_img, cfg.DIM_text, cfg.vocab_size, nrow]),
              "rec_stride": np.array(size // 64)}
     for k, v in sd.items():

@@ -1,0 +1,148 @@
+"""Host logic of mimic_amd (forward chains, hand-written backward chains, layouts, state_dict hooks,
+results schema) checked on CPU against the reference-generated goldens, with the HIP ops replaced by
+their torch emulation (tests/torch_backend.py).  The HIP kernels themselves are checked on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import mopoe_ref as R
+import torch_backend
+from golden_util import load, cfg_from, g0_state, g0_batch, g0_masks, checksums
+from model_util import build_exp
+from mimic_amd import run_epochs as RE
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def check_against_g0(exp, g, mode, batch, device="cpu", grad_rtol=1e-3, grad_atol=1e-3, rtol=1e-4, atol=1e-5):
+    out = RE.basic_routine_epoch(exp, ({k: v.clone().to(device) for k, v in batch.items()}, None))
+    res, lat = out["results"], out["results"]["latents"]
+    for m in R.MOD_ORDER:
+        close(lat["modalities"][m][0], g[f"{mode}/enc/{m}/mu"], rtol, atol, m)
+        close(lat["modalities"][m][1], g[f"{mode}/enc/{m}/logvar"], rtol, atol, m)
+    assert list(lat["subsets"].keys()) == ["PA", "Lateral", "text", "Lateral_PA", "PA_text", "Lateral_text",
+                                           "Lateral_PA_text"]
+    for key, (mu, lv) in lat["subsets"].items():
+        close(mu, g[f"{mode}/subset/{key}/mu"], rtol, atol, key)
+        close(lv, g[f"{mode}/subset/{key}/logvar"], rtol, atol, key)
+    close(lat["mus"], g[f"{mode}/mus"], rtol, atol)
+    close(lat["logvars"], g[f"{mode}/logvars"], rtol, atol)
+    close(lat["weights"], g[f"{mode}/weights"])
+    close(lat["joint"][0], g[f"{mode}/joint/mu"], rtol, atol)
+    close(lat["joint"][1], g[f"{mode}/joint/logvar"], rtol, atol)
+    close(res["individual_divs"], g[f"{mode}/individual_divs"], rtol, atol)
+    close(res["joint_divergence"], g[f"{mode}/joint_divergence"], rtol, atol)
+    rs = int(g["rec_stride"])
+    for m in ("PA", "Lateral"):
+        close(res["rec"][m].loc[:, :, ::rs, ::rs], g[f"{mode}/rec/{m}"], 10 * rtol, 10 * atol, m)
+        np.testing.assert_allclose(checksums(res["rec"][m].loc), g[f"{mode}/recchk/{m}"], rtol=10 * rtol, atol=1e-3)
+    close(res["rec"]["text"].logits, g[f"{mode}/rec/text"], 10 * rtol, 10 * atol)
+    for k, v in out["klds"].items():
+        close(v, g[f"{mode}/klds/{k}"], rtol, atol, k)
+    for k, v in out["log_probs"].items():
+        close(v, g[f"{mode}/log_probs/{k}"], rtol, atol, k)
+    close(out["total_loss"], g[f"{mode}/total_loss"], rtol, atol)
+    exp.mm_vae.zero_grad()
+    out["total_loss"].backward()
+    grads = exp.mm_vae.reference_named_grads()
+    pre = f"{mode}/grad/"
+    names = [k[len(pre):] for k in g.files if k.startswith(pre)]
+    assert set(names) == set(grads.keys()), set(names) ^ set(grads.keys())
+    for name in names:
+        ref = g[pre + name]
+        scale = max(np.abs(ref).max(), 1e-3)
+        if name.endswith(".bias") and (pre + name[:-4] + "weight") in g.files:
+            scale = max(scale, np.abs(g[pre + name[:-4] + "weight"]).max())
+        np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=grad_rtol, atol=grad_atol * scale,
+                                   err_msg=name)
+    return out
+
+
+@pytest.mark.parametrize("size", [64, 128, 256])
+@pytest.mark.parametrize("mode", ["eval", "train_nodrop", "train"])
+def test_g0_host_logic(monkeypatch, size, mode):
+    torch_backend.install(monkeypatch)
+    g = load(f"g0_s{size}")
+    cfg = cfg_from(g["cfg"])
+    exp = build_exp(cfg, g0_state(g), "cpu", mode, masks=g0_masks(g) if mode == "train" else None,
+                    eps=torch.from_numpy(g[f"{mode}/eps"]))
+    check_against_g0(exp, g, mode, g0_batch(g))
+    if mode != "eval":  # BatchNorm running statistics side effect
+        sd = exp.mm_vae.state_dict()
+        pre = f"{mode}/buf/"
+        for k in [k for k in g.files if k.startswith(pre)]:
+            name = k[len(pre):]
+            if "resblock_7" in name or "resblock_8" in name:
+                continue
+            close(sd[name], g[k], 1e-4, 1e-5, name)
+        assert int(sd["encoder_pa.feature_extractor.resblock_1.0.bn1.num_batches_tracked"]) == 1
+
+
+def test_state_dict_roundtrip_reference_layout(monkeypatch):
+    torch_backend.install(monkeypatch)
+    g = load("g0_s64")
+    sd_ref = g0_state(g)
+    exp = build_exp(cfg_from(g["cfg"]), sd_ref, "cpu")
+    sd = exp.mm_vae.state_dict()
+    assert set(sd.keys()) == set(sd_ref.keys())  # the reference's key scheme
+    assert len(sd) == 627 - 0 or len(sd) > 500
+    for k, v in sd_ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        torch.testing.assert_close(sd[k], v, rtol=0, atol=0)
+
+
+def test_partial_modalities_inference(monkeypatch):
+    torch_backend.install(monkeypatch)
+    g = load("g2_edges")
+    cfg = cfg_from(g["partial/cfg"])
+    sd = R.init_state(cfg, seed=int(g["partial/seed_weights"]))
+    batch, _ = R.synthetic_batch(cfg, cfg.batch_size, seed=int(g["partial/seed_batch"]))
+    exp = build_exp(cfg, sd, "cpu", "eval")
+    for combo in (("PA",), ("text",), ("PA", "text"), ("Lateral", "text"), ("PA", "Lateral")):
+        tag = "+".join(combo)
+        with torch.no_grad():
+            lat = exp.mm_vae.inference({m: batch[m] for m in combo})
+        assert list(lat["subsets"].keys()) == list(g[f"partial/{tag}/keys"])
+        close(lat["mus"], g[f"partial/{tag}/mus"])
+        close(lat["logvars"], g[f"partial/{tag}/logvars"])
+        close(lat["weights"], g[f"partial/{tag}/weights"])
+        close(lat["joint"][0], g[f"partial/{tag}/joint_mu"])
+        close(lat["joint"][1], g[f"partial/{tag}/joint_logvar"])
+
+
+def test_g3_adam_trajectory_host(monkeypatch):
+    torch_backend.install(monkeypatch)
+    g = load("g3_traj")
+    cfg = cfg_from(g["cfg"])
+    exp = build_exp(cfg, R.init_state(cfg, seed=int(g["seed_weights"])), "cpu", "train_nodrop")
+    exp.flags.initial_learning_rate = float(g["lr"])
+    exp.set_optimizer()
+    losses = []
+    for step in range(3):
+        batch, _ = R.synthetic_batch(cfg, cfg.batch_size, seed=20 + step)
+        e = torch.from_numpy(g["eps"][step])
+        exp.mm_vae.eps_source = lambda b, d, dev, e=e: e
+        out = RE.train_step(exp, (batch, None))
+        losses.append(out["total_loss"].item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    sd = exp.mm_vae.state_dict()
+    close(sd["encoder_pa.feature_extractor.conv1.weight"], g["final/encoder_pa.feature_extractor.conv1.weight"],
+          1e-4, 1e-6)
+
+
+def test_scalar_pack_and_train_loop(monkeypatch):
+    torch_backend.install(monkeypatch)
+    cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=4)
+    exp = build_exp(cfg, R.init_state(cfg, seed=1), "cpu", "train")
+    exp.mm_vae.set_mask_replay(None)
+    exp.set_optimizer()
+    loader = [(R.synthetic_batch(cfg, 4, seed=s)[0], None) for s in range(3)]
+    out = RE.train(exp, loader)
+    assert out["steps"] == 3
+    assert len(out["last"]) == 2 + 7 + 3 + 6  # the 18 scalars the reference logs per step
+    assert all(np.isfinite(v) for v in out["last"].values())
+    ev = RE.test(0, exp, loader, max_steps=1)
+    assert np.isfinite(ev["total_loss"])

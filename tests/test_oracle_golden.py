@@ -59,7 +59,7 @@ def test_g0_full(size, mode):
             # a bias that feeds a train-mode BatchNorm has an analytically zero gradient; what the
             # reference stores is cancellation noise proportional to the layer's gradient scale
             scale = max(scale, np.abs(g[pre + name[:-4] + "weight"]).max())
-        np.testing.assert_allclose(got.numpy(), ref, rtol=2e-4, atol=1e-4 * scale, err_msg=name)
+        np.testing.assert_allclose(got.numpy(), ref, rtol=1e-3, atol=1e-3 * scale, err_msg=name)
     # dead parameters (text resblock_7/8) get no gradient in the reference either
     dead = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad and v.grad is None]
     assert all("resblock_7" in k or "resblock_8" in k for k in dead) and len(dead) == 24

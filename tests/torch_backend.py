@@ -1,0 +1,293 @@
+"""TEST INFRASTRUCTURE: plain-PyTorch emulation of every op in mimic_amd.ops (same signatures,
+same channels-last contracts), used
+  * on CPU to test the host-side orchestration (manual forward/backward chains, layouts, state_dict
+    hooks, DP glue) against the oracle without a GPU, by monkeypatching mimic_amd.ops, and
+  * on the GPU box as the per-kernel fp32 reference each HIP kernel is compared with.
+It is never imported by the product package.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from mimic_amd import ops as real_ops
+from mimic_amd.ops import Bn, Geom, Mask, RES_A, RES_B
+
+OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_reduce", "block_out_bwd",
+            "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
+            "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
+            "embedding_fwd", "embedding_bwd"]
+
+
+def install(monkeypatch):
+    """Route mimic_amd.ops.<op> to this module (pytest monkeypatch; undone after the test)."""
+    import sys
+    me = sys.modules[__name__]
+    for name in OP_NAMES:
+        monkeypatch.setattr(real_ops, name, getattr(me, name))
+
+
+# ---- helpers -----------------------------------------------------------------------------------
+def bn_coef(bn: Bn):
+    """-> mean, rstd, scale, shift (float32 [C])"""
+    if bn.mode == 1:
+        mean = bn.sums[0] / bn.count
+        var = bn.sums[1] / bn.count - mean * mean
+        rstd = 1.0 / torch.sqrt(var.clamp_min(0) + bn.eps)
+        mean, rstd = mean.float(), rstd.float()
+    else:
+        mean = bn.rmean
+        rstd = 1.0 / torch.sqrt(bn.rvar + bn.eps)
+    scale = bn.gamma * rstd
+    shift = bn.beta - mean * scale
+    return mean, rstd, scale, shift
+
+
+def _act(x, bn):
+    if bn is None:
+        return x
+    _, _, scale, shift = bn_coef(bn)
+    return torch.relu(x * scale + shift)
+
+
+def _mask_mult(y, mask: Mask):
+    if mask is None:
+        return None
+    if mask.kind == 1:
+        n = mask.mask.shape[0]
+        return mask.mask.view(n, *([1] * (y.dim() - 2)), y.shape[-1])
+    return mask.mask.view(y.shape)
+
+
+def _ref_weight(wp, g: Geom):
+    """packed [taps, Cin, Cout] -> torch layout for conv2d / conv_transpose2d"""
+    w = wp.view(g.kh, g.kw, g.Cin, g.Cout)
+    if g.transposed:
+        return w.permute(2, 3, 0, 1).contiguous()  # [Cin, Cout, kh, kw]
+    return w.permute(3, 2, 0, 1).contiguous()      # [Cout, Cin, kh, kw]
+
+
+def _conv_nchw(x_nchw, w, g: Geom):
+    if g.transposed:
+        oph = g.Hb - ((g.Hs - 1) * g.sh - 2 * g.ph + g.kh)
+        opw = g.Wb - ((g.Ws - 1) * g.sw - 2 * g.pw + g.kw)
+        return F.conv_transpose2d(x_nchw, w, None, stride=(g.sh, g.sw), padding=(g.ph, g.pw),
+                                  output_padding=(oph, opw))
+    return F.conv2d(x_nchw, w, None, stride=(g.sh, g.sw), padding=(g.ph, g.pw))
+
+
+def _accum(stats, y):
+    if stats is not None:
+        y2 = y.reshape(-1, y.shape[-1]).double()
+        stats[0] += y2.sum(0)
+        stats[1] += (y2 * y2).sum(0)
+
+
+# ---- convolution family ------------------------------------------------------------------------
+def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None):
+    assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
+    h = _act(x, bn_in).permute(0, 3, 1, 2)
+    y = _conv_nchw(h, _ref_weight(wp, g), g).permute(0, 2, 3, 1).contiguous()
+    assert tuple(y.shape) == g.out_shape, (y.shape, g)
+    if bias is not None:
+        y = y + bias
+    mm = _mask_mult(y, mask)
+    if mm is not None:
+        y = y * mm
+    _accum(out_stats, y)
+    return y
+
+
+def conv_dgrad(dy, wp, g: Geom, relu_bn=None, xin=None, bwd_sums=None):
+    x0 = torch.zeros(g.in_shape, dtype=dy.dtype, device=dy.device).permute(0, 3, 1, 2).requires_grad_(True)
+    with torch.enable_grad():
+        y = _conv_nchw(x0, _ref_weight(wp, g), g)
+    (dx,) = torch.autograd.grad(y, x0, dy.permute(0, 3, 1, 2))
+    dx = dx.permute(0, 2, 3, 1).contiguous()
+    if relu_bn is not None:
+        mean, rstd, scale, shift = bn_coef(relu_bn)
+        dx = dx * ((xin * scale + shift) > 0).to(dx.dtype)
+        if bwd_sums is not None:
+            xhat = (xin - mean) * rstd
+            bwd_sums[0] += dx.reshape(-1, dx.shape[-1]).double().sum(0)
+            bwd_sums[1] += (dx * xhat).reshape(-1, dx.shape[-1]).double().sum(0)
+    return dx
+
+
+def conv_wgrad(x, dy, g: Geom, bn_in=None):
+    h = _act(x, bn_in).permute(0, 3, 1, 2)
+    w0 = _ref_weight(torch.zeros(g.taps, g.Cin, g.Cout, dtype=x.dtype, device=x.device), g).requires_grad_(True)
+    with torch.enable_grad():
+        y = _conv_nchw(h, w0, g)
+    (dw,) = torch.autograd.grad(y, w0, dy.permute(0, 3, 1, 2))
+    if g.transposed:
+        dwp = dw.permute(2, 3, 0, 1)
+    else:
+        dwp = dw.permute(2, 3, 1, 0)
+    return dwp.reshape(g.taps, g.Cin, g.Cout).contiguous()
+
+
+# ---- residual-block glue -----------------------------------------------------------------------
+def block_out_fwd(s, m, bn_s, a=RES_A, b=RES_B, out_stats=None):
+    _, _, scale, shift = bn_coef(bn_s)
+    out = a * (s * scale + shift) + b * m
+    _accum(out_stats, out)
+    return out
+
+
+def bn_bwd_reduce(g, s, bn_s):
+    mean, rstd, _, _ = bn_coef(bn_s)
+    sums = torch.zeros(2, s.shape[-1], dtype=torch.float64, device=s.device)
+    g2 = g.reshape(-1, g.shape[-1])
+    shat = ((s - mean) * rstd).reshape(-1, g.shape[-1])
+    sums[0] = g2.double().sum(0)
+    sums[1] = (g2 * shat).double().sum(0)
+    return sums
+
+
+def _bn_bwd(dy, x, bn, sums):
+    mean, rstd, _, _ = bn_coef(bn)
+    if bn.mode == 1:
+        xhat = (x - mean) * rstd
+        k1 = (sums[0] / bn.count).float()
+        k2 = (sums[1] / bn.count).float()
+        return bn.gamma * rstd * (dy - k1 - xhat * k2)
+    return bn.gamma * rstd * dy
+
+
+def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False, want_colsum_ds=True):
+    dm = b * g
+    mm = _mask_mult(g, mask)
+    if mm is not None:
+        dm = dm * mm
+    ds = a * _bn_bwd(g, s, bn_s, sums)
+    dgamma = (a * sums[1]).float()
+    dbeta = (a * sums[0]).float()
+    c = g.shape[-1]
+    cdm = dm.reshape(-1, c).sum(0) if want_colsum_dm else None
+    cds = ds.reshape(-1, c).sum(0) if want_colsum_ds else None
+    return dm.contiguous(), ds.contiguous(), dgamma, dbeta, cdm, cds
+
+
+def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False):
+    dx = _bn_bwd(dy, x, bn, sums)
+    mm = _mask_mult(dx, mask)
+    if mm is not None:
+        dx = dx * mm
+    if add is not None:
+        dx = dx + add
+    cs = dx.reshape(-1, dx.shape[-1]).sum(0) if want_colsum else None
+    return dx.contiguous(), sums[1].float(), sums[0].float(), cs
+
+
+def bn_running_update(entries, momentum=0.1):
+    for sums, rm, rv, count in entries:
+        mean = sums[0] / count
+        var = (sums[1] / count - mean * mean).clamp_min(0)
+        unbiased = var * (count / max(count - 1, 1))
+        rm.mul_(1 - momentum).add_(momentum * mean.float())
+        rv.mul_(1 - momentum).add_(momentum * unbiased.float())
+
+
+def colsum(x):
+    return x.reshape(-1, x.shape[-1]).sum(0)
+
+
+# ---- latent space -------------------------------------------------------------------------------
+_MEMBER_ORDER = (1, 0, 2)  # sorted-by-name order inside a subset: Lateral, PA, text
+
+
+def _active_subsets(mu_in):
+    avail = sum(1 << i for i, t in enumerate(mu_in) if t is not None)
+    return [m for m in real_ops.SUBSET_MASKS if (m & ~avail) == 0]
+
+
+def _latent_core(mu_in, lv_in, eps, row_start, w, norm):
+    subsets = _active_subsets(mu_in)
+    mus, lvs = [], []
+    for sm in subsets:
+        members = [i for i in _MEMBER_ORDER if sm & (1 << i)]
+        var = [torch.exp(lv_in[i]) + 1e-8 for i in members]
+        T = [1.0 / v for v in var]
+        tsum = T[0]
+        msum = mu_in[members[0]] * T[0]
+        for j in range(1, len(members)):
+            tsum = tsum + T[j]
+            msum = msum + mu_in[members[j]] * T[j]
+        mus.append(msum / tsum)
+        lvs.append(torch.log(1.0 / tsum))
+    mus, lvs = torch.stack(mus), torch.stack(lvs)
+    k = len(subsets)
+    jm = torch.cat([mus[i, row_start[i]:row_start[i + 1]] for i in range(k)])
+    jl = torch.cat([lvs[i, row_start[i]:row_start[i + 1]] for i in range(k)])
+    z = eps * torch.exp(0.5 * jl) + jm
+    klds = torch.stack([-0.5 * torch.sum(1 - lvs[i].exp() - mus[i].pow(2) + lvs[i]) / norm for i in range(k)])
+    jd = (torch.tensor(list(w), dtype=klds.dtype, device=klds.device) * klds).sum().reshape(1)
+    return mus, lvs, jm, jl, z, klds, jd
+
+
+def latent_fwd(mu_in, lv_in, eps, row_start, w, norm):
+    with torch.no_grad():
+        return _latent_core(mu_in, lv_in, eps, row_start, w, norm)
+
+
+def latent_bwd(mu_in, lv_in, eps, row_start, w, norm, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd):
+    mu_l = [None if t is None else t.detach().clone().requires_grad_(True) for t in mu_in]
+    lv_l = [None if t is None else t.detach().clone().requires_grad_(True) for t in lv_in]
+    with torch.enable_grad():
+        outs = _latent_core(mu_l, lv_l, eps, row_start, w, norm)
+        total = 0.0
+        for o, g in zip(outs, (g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd)):
+            if g is not None:
+                total = total + (o * g).sum()
+    leaves = [t for t in mu_l + lv_l if t is not None]
+    grads = torch.autograd.grad(total, leaves, allow_unused=True)
+    it = iter(grads)
+    dmu = [None if t is None else next(it) for t in mu_l]
+    dlv = [None if t is None else next(it) for t in lv_l]
+    fix = lambda g, t: torch.zeros_like(t) if g is None else g
+    return ([None if t is None else fix(g, t) for g, t in zip(dmu, mu_l)],
+            [None if t is None else fix(g, t) for g, t in zip(dlv, lv_l)])
+
+
+# ---- likelihoods, embedding -----------------------------------------------------------------------
+def laplace_nll_fwd(x_hat, x, scale, norm):
+    v = (math.log(2 * scale) + (x - x_hat).abs() / scale).double().sum() / norm
+    return v.float().reshape(1)
+
+
+def laplace_nll_bwd(x_hat, x, g, scale, norm):
+    return g * torch.sign(x_hat - x) / (scale * norm)
+
+
+def logsoftmax_fwd(x, inplace=False):
+    return F.log_softmax(x, dim=-1)
+
+
+def logsoftmax_bwd(dy, y, inplace=False):
+    return dy - torch.exp(y) * dy.sum(-1, keepdim=True)
+
+
+def token_nll_fwd(logp, ids, norm):
+    picked = torch.gather(logp.reshape(-1, logp.shape[-1]), 1, ids.reshape(-1, 1).long())
+    return (-(picked.double().sum()) / norm).float().reshape(1)
+
+
+def token_nll_bwd(ids, g, shape, norm):
+    d = torch.zeros(shape, dtype=torch.float32, device=ids.device)
+    d.reshape(-1, shape[-1]).scatter_(1, ids.reshape(-1, 1).long(), (-g / norm).expand(ids.numel(), 1))
+    return d
+
+
+def embedding_fwd(ids, table):
+    return table[ids.long()]
+
+
+def embedding_bwd(ids, gout, vocab, padding_idx=0):
+    d = torch.zeros(vocab, gout.shape[-1], dtype=torch.float32, device=gout.device)
+    flat = ids.reshape(-1).long()
+    d.index_add_(0, flat, gout.reshape(-1, gout.shape[-1]))
+    d[padding_idx] = 0
+    return d
