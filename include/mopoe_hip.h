@@ -62,7 +62,7 @@ typedef struct {
   const float* beta;     /* [C] */
   const float* rmean;    /* [C] (mode 2) */
   const float* rvar;     /* [C] (mode 2) */
-  float inv_count;       /* 1 / rows (mode 1) */
+  double inv_count;      /* 1 / rows (mode 1) */
   float eps;
   int32_t C;
   int32_t mode;

@@ -1,0 +1,603 @@
+// Implicit-GEMM convolution family on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// All activations are channels-last row matrices [pixels][C]; weights are packed Wp[tap][Cin][Cout].
+//
+//   gather_gemm  : Y[M][Cn] = sum_taps  T(X)[gather(m, tap)][Ck] * W_tap[Ck][Cn]
+//       form 0 ("gather from the big grid"): Y lives on the conv's small grid, X on the big grid.
+//               conv forward, convT input-gradient.
+//       form 1 ("sub-pixel phases"):        Y lives on the big grid, X on the small grid; the output
+//               pixels are processed phase by phase (oy % sh, ox % sw) so that only taps that hit a
+//               real input pixel are multiplied.  convT forward, conv input-gradient.
+//   wgrad_gemm   : dWp[tap][Cin][Cout] = sum_pixels T(x)[..][Cin]^T * dy[..][Cout]
+//
+// Block = 256 threads = 4 waves in a 2x2 arrangement; a wave owns a (BM/2)x(BN/2) sub-tile made of
+// 32x32 MFMA tiles; K is consumed in chunks of 16 through double-buffered LDS tiles stored K-major
+// ([k][m], [k][n]) so that every MFMA operand read is a conflict-free ds_read_b32 of consecutive
+// lanes.  BatchNorm+ReLU of the operand, bias, dropout mask, BN statistics and the ReLU/BN backward
+// reductions are fused into the operand load / epilogue (see include/mopoe_hip.h).
+#include "common.hpp"
+
+namespace mopoe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int MAX_BN_C = 1024;
+constexpr int LDS_PAD = 4;
+
+struct GemmArgs {
+  const float* X;
+  const float* W;
+  float* Y;
+  const float* bias;
+  int N, Hx, Wx, Hy, Wy, Ck, Cn, Cin_w, Cout_w;
+  int kh, kw, sh, sw, ph, pw;
+  int form, w_nk;
+  int Hq, Wq;            // rows of one phase: N*Hq*Wq (form 0: Hq=Hy, Wq=Wy)
+  long rows_per_phase;
+  int vecA, vecB;        // 16-byte loads legal for the activation / weight operand
+  mopoe_bn_ref bn_in;
+  mopoe_mask_ref mask;
+  double* out_stats;
+  mopoe_bn_ref relu_bn;
+  const float* xin;
+  double* bwd_sums;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
+  // loads up to 4 consecutive floats starting at p; elements >= nvalid are zero
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid >= 4 && vec) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GemmArgs a) {
+  constexpr int WM = BM / 2, WN = BN / 2;         // wave tile
+  constexpr int TI = WM / 32, TJ = WN / 32;       // MFMA tiles per wave
+  constexpr int A_LD = BM + LDS_PAD, B_LD = BN + LDS_PAD;
+  constexpr int A_PER_THR = BM / 64;              // float4 loads per thread for the A tile
+  constexpr int B_PER_THR = BN / 64;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK][A_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][B_LD];
+  __shared__ float bnS[MAX_BN_C];
+  __shared__ float bnT[MAX_BN_C];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int phase = blockIdx.z;
+
+  // ---- phase / tap enumeration ---------------------------------------------------------------
+  int nty, ntx, ky0, kx0, kstep_y, kstep_x, dsgn, cy = 0, cx = 0, phy = 0, phx = 0;
+  if (a.form == 0) {
+    nty = a.kh; ntx = a.kw; ky0 = 0; kx0 = 0; kstep_y = 1; kstep_x = 1; dsgn = 1;
+  } else {
+    phy = phase / a.sw; phx = phase % a.sw;
+    const int ry = (phy + a.ph) % a.sh, rx = (phx + a.pw) % a.sw;
+    nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
+    ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
+    ky0 = ry; kx0 = rx; kstep_y = a.sh; kstep_x = a.sw; dsgn = -1;
+    cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
+  }
+  const int nkc = (a.Ck + BK - 1) / BK;
+  const int total = nty * ntx * nkc;
+
+  // ---- BN(+ReLU) table for the operand transform -----------------------------------------------
+  const bool xform = a.bn_in.mode != 0;
+  if (xform) {
+    for (int c = tid; c < a.Ck; c += 256) {
+      const BnC k = bn_coef(a.bn_in, c);
+      bnS[c] = k.scale;
+      bnT[c] = k.shift;
+    }
+  }
+
+  // ---- per-thread A rows ---------------------------------------------------------------------------
+  const int kq = tid & 3;
+  int rn[A_PER_THR], ry0[A_PER_THR], rx0[A_PER_THR];
+  bool rvalid[A_PER_THR];
+#pragma unroll
+  for (int i = 0; i < A_PER_THR; ++i) {
+    const long m = m0 + (tid >> 2) + i * 64;
+    rvalid[i] = m < a.rows_per_phase;
+    const long mm = rvalid[i] ? m : 0;
+    const int hw = a.Hq * a.Wq;
+    const int n = (int)(mm / hw);
+    const int rem = (int)(mm - (long)n * hw);
+    const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
+    rn[i] = n;
+    if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
+    else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
+  }
+
+  float4 ra[A_PER_THR], rb[B_PER_THR];
+
+  auto load_tiles = [&](int it) {
+    const int tap = it / nkc;
+    const int kc = (it - tap * nkc) * BK;
+    const int jy = tap / ntx, jx = tap - jy * ntx;
+    const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+    // A: gathered activation rows
+    const int ck = kc + kq * 4;
+    const int nvk = a.Ck - ck;
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
+      const bool ok = rvalid[i] && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && nvk > 0;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const long row = ((long)rn[i] * a.Hx + iy) * a.Wx + ix;
+        v = ld4(a.X + row * a.Ck + ck, nvk, a.vecA);
+        if (xform) {
+          v.x = fmaxf(fmaf(v.x, bnS[ck], bnT[ck]), 0.f);
+          if (nvk > 1) v.y = fmaxf(fmaf(v.y, bnS[ck + 1], bnT[ck + 1]), 0.f);
+          if (nvk > 2) v.z = fmaxf(fmaf(v.z, bnS[ck + 2], bnT[ck + 2]), 0.f);
+          if (nvk > 3) v.w = fmaxf(fmaf(v.w, bnS[ck + 3], bnT[ck + 3]), 0.f);
+        }
+      }
+      ra[i] = v;
+    }
+    // B: weights
+    if (a.w_nk == 0) {
+      // W[(wtap*Cin_w + k)*Cout_w + n], n contiguous; tile rows = k
+      constexpr int N4 = BN / 4;  // float4 per k-row
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) {
+        const int k = tid / N4 + i * (256 / N4);
+        const int n = n0 + (tid % N4) * 4;
+        const int kk = kc + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < a.Ck && n < a.Cn)
+          v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, a.vecB);
+        rb[i] = v;
+      }
+    } else {
+      // W[(wtap*Cin_w + n)*Cout_w + k], k contiguous; tile rows = n
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) {
+        const int n = n0 + (tid >> 2) + i * 64;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < a.Cn && nvk > 0)
+          v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, a.vecB);
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const int r = (tid >> 2) + i * 64;
+      As[buf][kq * 4 + 0][r] = ra[i].x;
+      As[buf][kq * 4 + 1][r] = ra[i].y;
+      As[buf][kq * 4 + 2][r] = ra[i].z;
+      As[buf][kq * 4 + 3][r] = ra[i].w;
+    }
+    if (a.w_nk == 0) {
+      constexpr int N4 = BN / 4;
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) {
+        const int k = tid / N4 + i * (256 / N4);
+        *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) {
+        const int r = (tid >> 2) + i * 64;
+        Bs[buf][kq * 4 + 0][r] = rb[i].x;
+        Bs[buf][kq * 4 + 1][r] = rb[i].y;
+        Bs[buf][kq * 4 + 2][r] = rb[i].z;
+        Bs[buf][kq * 4 + 3][r] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (xform) __syncthreads();  // bnS/bnT visible before the first transform
+  if (total > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int it = 0; it < total; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < total) load_tiles(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + lhi;
+      float av[TI], bv[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) av[i] = As[cur][k][wm * WM + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bv[j] = Bs[cur][k][wn * WN + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < total) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------
+  const bool do_relu_bn = a.relu_bn.mode != 0;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int n = n0 + wn * WN + j * 32 + l31;
+    const bool nok = n < a.Cn;
+    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+    BnC rb_c = {0.f, 0.f, 0.f, 0.f};
+    if (nok && do_relu_bn) rb_c = bn_coef(a.relu_bn, n);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (!nok || m >= a.rows_per_phase) continue;
+        long yrow;
+        if (a.form == 0) {
+          yrow = m;
+        } else {
+          const int hw = a.Hq * a.Wq;
+          const int nn = (int)(m / hw);
+          const int rem = (int)(m - (long)nn * hw);
+          const int py = rem / a.Wq, px = rem - py * a.Wq;
+          yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+        }
+        float v = acc[i][j][r] + bias;
+        if (a.mask.kind != 0) v *= mask_at(a.mask, yrow, n, a.Cn);
+        if (do_relu_bn) {
+          const float xi = a.xin[yrow * a.Cn + n];
+          v = (fmaf(xi, rb_c.scale, rb_c.shift) > 0.f) ? v : 0.f;
+          s1 += v;
+          s2 += v * ((xi - rb_c.mean) * rb_c.rstd);
+        } else {
+          s1 += v;
+          s2 += v * v;
+        }
+        a.Y[yrow * a.Cn + n] = v;
+      }
+    }
+    double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
+    if (sums) {
+      // lanes l and l+32 hold the same column
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (nok && lhi == 0) {
+        atomic_add_f64(sums + n, (double)s1);
+        atomic_add_f64(sums + a.Cn + n, (double)s2);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// weight gradient
+// =====================================================================================================
+struct WgradArgs {
+  const float* Xs;   // layer input  x  [rows][Cin]
+  const float* Dy;   // output grad  dy [rows][Cout]
+  float* dW;         // [taps][Cin][Cout]
+  int N, Hs, Ws, Hb, Wb, Cin, Cout, kh, kw, sh, sw, ph, pw;
+  int x_is_big;      // 1: conv (x on the big grid, gathered); 0: convT (dy on the big grid, gathered)
+  long Ms;           // N*Hs*Ws pixels of the small grid (the reduction length)
+  long chunk;        // pixels per split (multiple of BK)
+  int nJ;            // number of J (Cout) tiles
+  int atomic;        // 1: accumulate with atomics (split reduction)
+  int vecI, vecJ;
+  mopoe_bn_ref bn_in;
+};
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
+  constexpr int WI = BI / 2, WJ = BJ / 2;
+  constexpr int TI = WI / 32, TJ = WJ / 32;
+  constexpr int I_LD = BI + LDS_PAD, J_LD = BJ + LDS_PAD;
+  constexpr int I4 = BI / 4, J4 = BJ / 4;          // float4 per pixel row
+  constexpr int I_PER_THR = (BK * I4) / 256, J_PER_THR = (BK * J4) / 256;
+
+  __shared__ __attribute__((aligned(16))) float Is[2][BK][I_LD];
+  __shared__ __attribute__((aligned(16))) float Js[2][BK][J_LD];
+  __shared__ float bnS[MAX_BN_C];
+  __shared__ float bnT[MAX_BN_C];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int it_i = blockIdx.x / a.nJ, it_j = blockIdx.x % a.nJ;
+  const int i0 = it_i * BI, j0 = it_j * BJ;
+  const int tap = blockIdx.y;
+  const int ky = tap / a.kw, kx = tap % a.kw;
+  const long mbeg = (long)blockIdx.z * a.chunk;
+  const long mend = mbeg + a.chunk < a.Ms ? mbeg + a.chunk : a.Ms;
+  const int total = (int)((mend - mbeg + BK - 1) / BK);
+
+  const bool xform = a.bn_in.mode != 0;
+  if (xform) {
+    for (int c = tid; c < a.Cin; c += 256) {
+      const BnC k = bn_coef(a.bn_in, c);
+      bnS[c] = k.scale;
+      bnT[c] = k.shift;
+    }
+    __syncthreads();
+  }
+
+  float4 ri[I_PER_THR], rj[J_PER_THR];
+  const int hw = a.Hs * a.Ws;
+
+  // row index of pixel m in the small tensor (direct) and in the big tensor (gathered, -1 if padding)
+  auto rows_of = [&](long m, long& small_row, long& big_row) {
+    small_row = m;
+    const int n = (int)(m / hw);
+    const int rem = (int)(m - (long)n * hw);
+    const int qy = rem / a.Ws, qx = rem - qy * a.Ws;
+    const int by = qy * a.sh - a.ph + ky, bx = qx * a.sw - a.pw + kx;
+    big_row = (by >= 0 && by < a.Hb && bx >= 0 && bx < a.Wb) ? ((long)n * a.Hb + by) * a.Wb + bx : -1;
+  };
+
+  auto load_tiles = [&](int it) {
+    const long mb = mbeg + (long)it * BK;
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const int p = tid / I4 + t * (256 / I4);
+      const int c = i0 + (tid % I4) * 4;
+      const long m = mb + p;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < mend && c < a.Cin) {
+        long srow, brow;
+        rows_of(m, srow, brow);
+        const long row = a.x_is_big ? brow : srow;
+        if (row >= 0) {
+          const int nv = a.Cin - c;
+          v = ld4(a.Xs + row * a.Cin + c, nv, a.vecI);
+          if (xform) {
+            v.x = fmaxf(fmaf(v.x, bnS[c], bnT[c]), 0.f);
+            if (nv > 1) v.y = fmaxf(fmaf(v.y, bnS[c + 1], bnT[c + 1]), 0.f);
+            if (nv > 2) v.z = fmaxf(fmaf(v.z, bnS[c + 2], bnT[c + 2]), 0.f);
+            if (nv > 3) v.w = fmaxf(fmaf(v.w, bnS[c + 3], bnT[c + 3]), 0.f);
+          }
+        }
+      }
+      ri[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < J_PER_THR; ++t) {
+      const int p = tid / J4 + t * (256 / J4);
+      const int c = j0 + (tid % J4) * 4;
+      const long m = mb + p;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < mend && c < a.Cout) {
+        long srow, brow;
+        rows_of(m, srow, brow);
+        const long row = a.x_is_big ? srow : brow;
+        if (row >= 0) v = ld4(a.Dy + row * a.Cout + c, a.Cout - c, a.vecJ);
+      }
+      rj[t] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const int p = tid / I4 + t * (256 / I4);
+      *reinterpret_cast<float4*>(&Is[buf][p][(tid % I4) * 4]) = ri[t];
+    }
+#pragma unroll
+    for (int t = 0; t < J_PER_THR; ++t) {
+      const int p = tid / J4 + t * (256 / J4);
+      *reinterpret_cast<float4*>(&Js[buf][p][(tid % J4) * 4]) = rj[t];
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (total > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int it = 0; it < total; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < total) load_tiles(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + lhi;
+      float av[TI], bv[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) av[i] = Is[cur][k][wi * WI + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bv[j] = Js[cur][k][wj * WJ + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < total) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int co = j0 + wj * WJ + j * 32 + l31;
+    if (co >= a.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = i0 + wi * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (ci >= a.Cin) continue;
+        float* dst = a.dW + ((long)tap * a.Cin + ci) * a.Cout + co;
+        if (a.atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+        else *dst = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// host-side launchers
+// =====================================================================================================
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int validate_geom(const mopoe_conv_geom* g) {
+  if (!g || g->N <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->Hb <= 0 || g->Wb <= 0 || g->Cin <= 0 || g->Cout <= 0 ||
+      g->kh <= 0 || g->kw <= 0 || g->sh <= 0 || g->sw <= 0 || g->ph < 0 || g->pw < 0) {
+    set_error("conv geometry: non-positive field");
+    return MOPOE_ERR_ARG;
+  }
+  if (g->Hb % g->sh != 0 || g->Wb % g->sw != 0) {
+    set_error("conv geometry: big grid (%d,%d) must be a multiple of the stride (%d,%d)", g->Hb, g->Wb, g->sh, g->sw);
+    return MOPOE_ERR_ARG;
+  }
+  // every small-grid pixel must map inside the padded big grid
+  if ((g->Hs - 1) * g->sh - g->ph + g->kh - 1 >= g->Hb + g->ph + g->sh || (g->Ws - 1) * g->sw - g->pw + g->kw - 1 >= g->Wb + g->pw + g->sw) {
+    set_error("conv geometry: small grid does not fit the big grid");
+    return MOPOE_ERR_ARG;
+  }
+  return 0;
+}
+
+// dest_on_small: 1 -> form 0 (Y on the small grid), 0 -> form 1 (Y on the big grid)
+static int launch_gather(const float* X, const float* W, const float* bias, float* Y, const mopoe_conv_geom* g,
+                         int dest_on_small, int Ck, int Cn, int w_nk, const mopoe_bn_ref* bn_in,
+                         const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
+                         const float* xin, double* bwd_sums, hipStream_t stream) {
+  GemmArgs a;
+  a.X = X; a.W = W; a.Y = Y; a.bias = bias;
+  a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;
+  a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+  a.w_nk = w_nk;
+  int nphase;
+  if (dest_on_small) {
+    a.form = 0; a.Hx = g->Hb; a.Wx = g->Wb; a.Hy = g->Hs; a.Wy = g->Ws; a.Hq = g->Hs; a.Wq = g->Ws; nphase = 1;
+  } else {
+    a.form = 1; a.Hx = g->Hs; a.Wx = g->Ws; a.Hy = g->Hb; a.Wy = g->Wb; a.Hq = g->Hb / g->sh; a.Wq = g->Wb / g->sw;
+    nphase = g->sh * g->sw;
+  }
+  a.rows_per_phase = (long)g->N * a.Hq * a.Wq;
+  a.vecA = (Ck % 4 == 0) && aligned16(X);
+  a.vecB = (g->Cout % 4 == 0) && aligned16(W);
+  mopoe_bn_ref none = {};
+  mopoe_mask_ref nomask = {nullptr, 0, 1};
+  a.bn_in = bn_in ? *bn_in : none;
+  a.mask = mask ? *mask : nomask;
+  a.out_stats = out_stats;
+  a.relu_bn = relu_bn ? *relu_bn : none;
+  a.xin = xin; a.bwd_sums = bwd_sums;
+  if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
+  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
+  if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
+
+  // tile choice: big tiles when they still fill the chip, else 64x64
+  const long tiles128 = (long)ceil_div(a.rows_per_phase, 128) * ceil_div(Cn, 128) * nphase;
+  const bool big = tiles128 >= 192 && Cn > 64;
+  // algorithmic flops: every (output pixel, tap that exists) pair
+  double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
+  const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
+  ProfScope prof(stream, flops);
+  if (big) {
+    dim3 grid(ceil_div(a.rows_per_phase, 128), ceil_div(Cn, 128), nphase);
+    hipLaunchKernelGGL((gather_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
+  } else {
+    dim3 grid(ceil_div(a.rows_per_phase, 64), ceil_div(Cn, 64), nphase);
+    hipLaunchKernelGGL((gather_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+  }
+  return check_launch("gather_gemm");
+}
+
+}  // namespace mopoe
+
+using namespace mopoe;
+
+extern "C" int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const mopoe_conv_geom* g,
+                              const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats, void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !wp || !y) { set_error("conv_fwd: null pointer"); return MOPOE_ERR_ARG; }
+  // Conv: output on the small grid.  ConvTranspose: output on the big grid (phases).
+  return launch_gather(x, wp, bias, y, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask, out_stats,
+                       nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
+                                const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!dy || !wp || !dx) { set_error("conv_dgrad: null pointer"); return MOPOE_ERR_ARG; }
+  // input gradient of a Conv lives on the big grid (phases); of a ConvTranspose on the small grid.
+  return launch_gather(dy, wp, nullptr, dx, g, g->transposed ? 1 : 0, g->Cout, g->Cin, /*w_nk=*/1, nullptr, nullptr,
+                       nullptr, relu_bn, xin, bwd_sums, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
+                                const mopoe_bn_ref* bn_in, void* stream_) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !dy || !dwp) { set_error("conv_wgrad: null pointer"); return MOPOE_ERR_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradArgs a;
+  a.Xs = x; a.Dy = dy; a.dW = dwp;
+  a.N = g->N; a.Hs = g->Hs; a.Ws = g->Ws; a.Hb = g->Hb; a.Wb = g->Wb; a.Cin = g->Cin; a.Cout = g->Cout;
+  a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+  a.x_is_big = g->transposed ? 0 : 1;
+  a.Ms = (long)g->N * g->Hs * g->Ws;
+  mopoe_bn_ref none = {};
+  a.bn_in = bn_in ? *bn_in : none;
+  if (a.bn_in.mode != 0 && (a.bn_in.C != g->Cin || g->Cin > MAX_BN_C)) { set_error("wgrad bn_in channel mismatch"); return MOPOE_ERR_ARG; }
+  a.vecI = (g->Cin % 4 == 0) && aligned16(x);
+  a.vecJ = (g->Cout % 4 == 0) && aligned16(dy);
+  const int taps = g->kh * g->kw;
+  const bool big = g->Cin > 64 && g->Cout > 64;
+  const int T = big ? 128 : 64;
+  const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
+  a.nJ = nJ;
+  const long tiles = (long)nI * nJ * taps;
+  // split the pixel reduction until ~1024 blocks are in flight, keeping >= 8 K-chunks per block
+  long split = (1024 + tiles - 1) / tiles;
+  const long max_split = (a.Ms + 8 * BK - 1) / (8 * BK);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  long chunk = (a.Ms + split - 1) / split;
+  chunk = (chunk + BK - 1) / BK * BK;
+  split = (a.Ms + chunk - 1) / chunk;
+  a.chunk = chunk;
+  a.atomic = split > 1;
+  const size_t bytes = (size_t)taps * g->Cin * g->Cout * sizeof(float);
+  if (a.atomic) {
+    if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
+  }
+  const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
+  ProfScope prof(stream, flops);
+  dim3 grid(nI * nJ, taps, (unsigned)split);
+  if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+  return check_launch("wgrad_gemm");
+}

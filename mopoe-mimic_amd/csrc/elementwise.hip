@@ -1,0 +1,359 @@
+// HBM-bound glue kernels of the residual blocks: every tensor is a row-major [rows][C] matrix; a thread
+// owns a fixed group of VEC consecutive channels (so per-channel BatchNorm coefficients live in
+// registers) and walks rows with a grid stride; loads/stores are 16 bytes per lane when C % 4 == 0.
+// Column reductions (BN statistics, BN-backward sums, bias gradients) are reduced per block through
+// LDS and leave the block as one atomic per column.
+#include "common.hpp"
+
+namespace mopoe {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 2048;
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  float v[4];
+  __device__ static Vec ld(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    Vec r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+  }
+  __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Vec<1> {
+  float v[1];
+  __device__ static Vec ld(const float* p) { Vec r; r.v[0] = *p; return r; }
+  __device__ void st(float* p) const { *p = v[0]; }
+};
+
+// column layout of a block: `cols` vector-columns per pass, `rpp` rows per pass
+struct ColLayout {
+  int Cv, cols, rpp, tc, tr;
+  __device__ ColLayout(int C, int VEC) {
+    Cv = (C + VEC - 1) / VEC;
+    cols = Cv < EW_THREADS ? Cv : EW_THREADS;
+    rpp = EW_THREADS / cols;
+    tc = threadIdx.x % cols;
+    tr = threadIdx.x / cols;
+  }
+};
+
+// reduce NACC per-thread partials (per channel of the thread's vector) over the block's row dimension
+// and add them to out[k][channel] (double, atomics) or outf (float, atomics)
+template <int VEC, int NACC>
+__device__ void block_col_reduce(const ColLayout& L, bool active, int cbase, int C, float (&part)[NACC][VEC],
+                                 double* const (&outd)[NACC], float* const (&outf)[NACC]) {
+  __shared__ float red[EW_THREADS * NACC * VEC];
+  __syncthreads();
+  for (int k = 0; k < NACC; ++k)
+    for (int e = 0; e < VEC; ++e) red[(threadIdx.x * NACC + k) * VEC + e] = active ? part[k][e] : 0.f;
+  __syncthreads();
+  if (L.tr == 0 && L.tc < L.cols) {
+    for (int k = 0; k < NACC; ++k) {
+      if (!outd[k] && !outf[k]) continue;
+      for (int e = 0; e < VEC; ++e) {
+        const int c = (cbase + L.tc) * VEC + e;
+        if (c >= C) continue;
+        float s = 0.f;
+        for (int r = 0; r < L.rpp; ++r) s += red[((r * L.cols + L.tc) * NACC + k) * VEC + e];
+        if (outd[k]) atomic_add_f64(outd[k] + c, (double)s);
+        if (outf[k]) unsafeAtomicAdd(outf[k] + c, s);
+      }
+    }
+  }
+}
+
+// ---- out = a*bn(s) + b*m  (+ stats of out) -----------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const float* s, const float* m, float* out, long rows,
+                                                                 int C, mopoe_bn_ref bn, float a, float b, double* stats) {
+  const ColLayout L(C, VEC);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float sc[VEC], sh[VEC], part[2][VEC];
+    for (int e = 0; e < VEC; ++e) {
+      sc[e] = sh[e] = 0.f; part[0][e] = part[1][e] = 0.f;
+      const int c = cv * VEC + e;
+      if (active && c < C) { const BnC k = bn_coef(bn, c); sc[e] = a * k.scale; sh[e] = a * k.shift; }
+    }
+    if (active) {
+      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
+        const long off = r * C + (long)cv * VEC;
+        const Vec<VEC> vs = Vec<VEC>::ld(s + off), vm = Vec<VEC>::ld(m + off);
+        Vec<VEC> o;
+        for (int e = 0; e < VEC; ++e) {
+          o.v[e] = fmaf(vs.v[e], sc[e], sh[e]) + b * vm.v[e];
+          part[0][e] += o.v[e];
+          part[1][e] += o.v[e] * o.v[e];
+        }
+        o.st(out + off);
+      }
+    }
+    if (stats) {
+      double* const od[2] = {stats, stats + C};
+      float* const of[2] = {nullptr, nullptr};
+      block_col_reduce<VEC, 2>(L, active, cbase, C, part, od, of);
+    }
+  }
+}
+
+// ---- sums += {sum g, sum g*shat} -----------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float* g, const float* s, long rows, int C,
+                                                                 mopoe_bn_ref bn, double* sums) {
+  const ColLayout L(C, VEC);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float mean[VEC], rstd[VEC], part[2][VEC];
+    for (int e = 0; e < VEC; ++e) {
+      mean[e] = rstd[e] = 0.f; part[0][e] = part[1][e] = 0.f;
+      const int c = cv * VEC + e;
+      if (active && c < C) { const BnC k = bn_coef(bn, c); mean[e] = k.mean; rstd[e] = k.rstd; }
+    }
+    if (active) {
+      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
+        const long off = r * C + (long)cv * VEC;
+        const Vec<VEC> vg = Vec<VEC>::ld(g + off), vs = Vec<VEC>::ld(s + off);
+        for (int e = 0; e < VEC; ++e) {
+          part[0][e] += vg.v[e];
+          part[1][e] += vg.v[e] * ((vs.v[e] - mean[e]) * rstd[e]);
+        }
+      }
+    }
+    double* const od[2] = {sums, sums + C};
+    float* const of[2] = {nullptr, nullptr};
+    block_col_reduce<VEC, 2>(L, active, cbase, C, part, od, of);
+  }
+}
+
+// ---- dm = b*g*mask ; ds = a*BNbwd(g; s) ---------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* g, const float* s, float* dm, float* ds,
+                                                                 long rows, int C, mopoe_bn_ref bn, const double* sums,
+                                                                 mopoe_mask_ref mask, float a, float b, float* dgamma,
+                                                                 float* dbeta, float* colsum_dm, float* colsum_ds) {
+  const ColLayout L(C, VEC);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float mean[VEC], rstd[VEC], gr[VEC], k1[VEC], k2[VEC], part[2][VEC];
+    for (int e = 0; e < VEC; ++e) {
+      mean[e] = rstd[e] = gr[e] = k1[e] = k2[e] = 0.f; part[0][e] = part[1][e] = 0.f;
+      const int c = cv * VEC + e;
+      if (active && c < C) {
+        const BnC k = bn_coef(bn, c);
+        mean[e] = k.mean; rstd[e] = k.rstd; gr[e] = a * k.scale;  // a * gamma * rstd
+        if (bn.mode == 1) { k1[e] = (float)(sums[c] * bn.inv_count); k2[e] = (float)(sums[C + c] * bn.inv_count); }
+        if (blockIdx.x == 0 && L.tr == 0) {
+          dgamma[c] = a * (float)sums[C + c];
+          dbeta[c] = a * (float)sums[c];
+        }
+      }
+    }
+    if (active) {
+      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
+        const long off = r * C + (long)cv * VEC;
+        const Vec<VEC> vg = Vec<VEC>::ld(g + off), vs = Vec<VEC>::ld(s + off);
+        Vec<VEC> om, os;
+        for (int e = 0; e < VEC; ++e) {
+          float mk = 1.f;
+          if (mask.kind != 0) mk = mask_at(mask, r, cv * VEC + e, C);
+          om.v[e] = b * vg.v[e] * mk;
+          const float shat = (vs.v[e] - mean[e]) * rstd[e];
+          os.v[e] = gr[e] * (vg.v[e] - k1[e] - shat * k2[e]);
+          part[0][e] += om.v[e];
+          part[1][e] += os.v[e];
+        }
+        om.st(dm + off);
+        os.st(ds + off);
+      }
+    }
+    if (colsum_dm || colsum_ds) {
+      double* const od[2] = {nullptr, nullptr};
+      float* const of[2] = {colsum_dm, colsum_ds};
+      block_col_reduce<VEC, 2>(L, active, cbase, C, part, od, of);
+    }
+  }
+}
+
+// ---- dx = mask * BNbwd(dy; x) + add --------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* dy, const float* x, const float* add,
+                                                                float* dx, long rows, int C, mopoe_bn_ref bn,
+                                                                const double* sums, mopoe_mask_ref mask, float* dgamma,
+                                                                float* dbeta, float* colsum_dx) {
+  const ColLayout L(C, VEC);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float mean[VEC], rstd[VEC], gr[VEC], k1[VEC], k2[VEC], part[1][VEC];
+    for (int e = 0; e < VEC; ++e) {
+      mean[e] = rstd[e] = gr[e] = k1[e] = k2[e] = 0.f; part[0][e] = 0.f;
+      const int c = cv * VEC + e;
+      if (active && c < C) {
+        const BnC k = bn_coef(bn, c);
+        mean[e] = k.mean; rstd[e] = k.rstd; gr[e] = k.scale;
+        if (bn.mode == 1) { k1[e] = (float)(sums[c] * bn.inv_count); k2[e] = (float)(sums[C + c] * bn.inv_count); }
+        if (blockIdx.x == 0 && L.tr == 0) {
+          dgamma[c] = (float)sums[C + c];
+          dbeta[c] = (float)sums[c];
+        }
+      }
+    }
+    if (active) {
+      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
+        const long off = r * C + (long)cv * VEC;
+        const Vec<VEC> vd = Vec<VEC>::ld(dy + off), vx = Vec<VEC>::ld(x + off);
+        Vec<VEC> va, o;
+        if (add) va = Vec<VEC>::ld(add + off);
+        for (int e = 0; e < VEC; ++e) {
+          const float xhat = (vx.v[e] - mean[e]) * rstd[e];
+          float v = gr[e] * (vd.v[e] - k1[e] - xhat * k2[e]);
+          if (mask.kind != 0) v *= mask_at(mask, r, cv * VEC + e, C);
+          if (add) v += va.v[e];
+          o.v[e] = v;
+          part[0][e] += v;
+        }
+        o.st(dx + off);
+      }
+    }
+    if (colsum_dx) {
+      double* const od[1] = {nullptr};
+      float* const of[1] = {colsum_dx};
+      block_col_reduce<VEC, 1>(L, active, cbase, C, part, od, of);
+    }
+  }
+}
+
+// ---- column sums -----------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* x, float* out, long rows, int C) {
+  const ColLayout L(C, VEC);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float part[1][VEC];
+    for (int e = 0; e < VEC; ++e) part[0][e] = 0.f;
+    if (active) {
+      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
+        const Vec<VEC> v = Vec<VEC>::ld(x + r * C + (long)cv * VEC);
+        for (int e = 0; e < VEC; ++e) part[0][e] += v.v[e];
+      }
+    }
+    double* const od[1] = {nullptr};
+    float* const of[1] = {out};
+    block_col_reduce<VEC, 1>(L, active, cbase, C, part, od, of);
+  }
+}
+
+// ---- running statistics ------------------------------------------------------------------------------------
+__global__ void bn_running_kernel(const mopoe_bn_running_desc* desc, float momentum) {
+  const mopoe_bn_running_desc d = desc[blockIdx.x];
+  const double inv = 1.0 / (double)d.count;
+  const double unb = d.count > 1 ? (double)d.count / (double)(d.count - 1) : 1.0;
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const double m = d.sums[c] * inv;
+    double v = d.sums[d.C + c] * inv - m * m;
+    v = v < 0.0 ? 0.0 : v;
+    d.rmean[c] = (1.f - momentum) * d.rmean[c] + momentum * (float)m;
+    d.rvar[c] = (1.f - momentum) * d.rvar[c] + momentum * (float)(v * unb);
+  }
+}
+
+static int ew_grid(long rows, int C, int VEC) {
+  const int Cv = (C + VEC - 1) / VEC;
+  const int cols = Cv < EW_THREADS ? Cv : EW_THREADS;
+  const int rpp = EW_THREADS / cols;
+  long blocks = (rows + rpp - 1) / rpp;
+  // keep several rows per thread so the per-block reduction / atomics amortise
+  blocks = (blocks + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  if (blocks > EW_MAX_BLOCKS) blocks = EW_MAX_BLOCKS;
+  return (int)blocks;
+}
+
+static bool vec_ok(int C, std::initializer_list<const void*> ptrs) {
+  if (C % 4 != 0) return false;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+  return true;
+}
+
+}  // namespace mopoe
+
+using namespace mopoe;
+
+#define EW_ARGCHECK(cond, msg) \
+  if (!(cond)) { set_error(msg); return MOPOE_ERR_ARG; }
+
+extern "C" int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
+                                   const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream) {
+  EW_ARGCHECK(s && m && out && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0, "block_out_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, {s, m, out}))
+    hipLaunchKernelGGL(block_out_fwd_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+  else
+    hipLaunchKernelGGL(block_out_fwd_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+  return check_launch("block_out_fwd");
+}
+
+extern "C" int mopoe_bn_bwd_reduce(const float* g, const float* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,
+                                   double* sums, void* stream) {
+  EW_ARGCHECK(g && s && sums && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0, "bn_bwd_reduce: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, {g, s}))
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int mopoe_block_out_bwd(const float* g, const float* s, float* dm, float* ds, int64_t rows, int32_t C,
+                                   const mopoe_bn_ref* bn_s, const double* sums, const mopoe_mask_ref* mask, float a,
+                                   float b, float* dgamma, float* dbeta, float* colsum_dm, float* colsum_ds,
+                                   void* stream) {
+  EW_ARGCHECK(g && s && dm && ds && sums && dgamma && dbeta && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0,
+              "block_out_bwd: bad arguments");
+  mopoe_mask_ref mk = mask ? *mask : mopoe_mask_ref{nullptr, 0, 1};
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, {g, s, dm, ds}))
+    hipLaunchKernelGGL(block_out_bwd_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+  else
+    hipLaunchKernelGGL(block_out_bwd_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+  return check_launch("block_out_bwd");
+}
+
+extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows, int32_t C,
+                                  const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask, float* dgamma,
+                                  float* dbeta, float* colsum_dx, void* stream) {
+  EW_ARGCHECK(dy && x && dx && sums && dgamma && dbeta && bn && bn->mode != 0 && bn->C == C && rows > 0,
+              "bn_bwd_apply: bad arguments");
+  mopoe_mask_ref mk = mask ? *mask : mopoe_mask_ref{nullptr, 0, 1};
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(C, {dy, x, add, dx}))
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx);
+  return check_launch("bn_bwd_apply");
+}
+
+extern "C" int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_t n, float momentum, void* stream) {
+  EW_ARGCHECK(desc && n > 0, "bn_running_update: bad arguments");
+  hipLaunchKernelGGL(bn_running_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, desc, momentum);
+  return check_launch("bn_running_update");
+}
+
+extern "C" int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream) {
+  EW_ARGCHECK(x && out && rows > 0 && C > 0, "colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
+  if (vec_ok(C, {x}))
+    hipLaunchKernelGGL(colsum_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+  else
+    hipLaunchKernelGGL(colsum_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+  return check_launch("colsum");
+}

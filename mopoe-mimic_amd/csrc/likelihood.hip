@@ -1,0 +1,273 @@
+// Likelihood reductions and the text-side row kernels.
+//   Laplace NLL (image modalities), row-wise log-softmax over the vocabulary, token NLL gather
+//   (OneHotCategorical without the one-hot), embedding gather / scatter-add.
+// All are HBM-bound streaming kernels: 16-byte loads where alignment allows, wavefront-shuffle
+// reductions, one double atomic per block; scalar results are finalised by the last block.
+#include "common.hpp"
+
+namespace mopoe {
+
+// finalise a scalar reduction: ws[0] = running double sum, ws[1] = arrival counter (both left zero)
+__device__ __forceinline__ void finish_scalar(double block_sum, double* ws, int nblocks, float scale, float* out) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    atomic_add_f64(ws, block_sum);
+    __threadfence();
+    const unsigned prev = atomicAdd(reinterpret_cast<unsigned*>(ws + 1), 1u);
+    is_last = (prev == (unsigned)(nblocks - 1));
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __threadfence();
+    const double s = __hip_atomic_load(ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[0] = (float)(s * (double)scale);
+    __hip_atomic_store(ws, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(ws + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ double block_sum_256(float v) {
+  __shared__ double part[4];
+  const double s = wave_sum_d((double)v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return part[0] + part[1] + part[2] + part[3];
+}
+
+// ---- Laplace ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void laplace_nll_fwd_kernel(const float* xh, const float* x, long n, float inv_scale,
+                                                            float log2b, float inv_norm, float* out, double* ws,
+                                                            int nblocks, int vec) {
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      const float4 a = reinterpret_cast<const float4*>(xh)[i], b = reinterpret_cast<const float4*>(x)[i];
+      acc += fabsf(b.x - a.x) + fabsf(b.y - a.y) + fabsf(b.z - a.z) + fabsf(b.w - a.w);
+    }
+    // tail (n % 4 elements)
+    const long t = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) acc += fabsf(x[t] - xh[t]);
+  } else {
+    for (; i < n; i += stride) acc += fabsf(x[i] - xh[i]);
+  }
+  const double bs = block_sum_256(acc);
+  // sum over elements of (log(2b) + |x - xh|/b) / norm
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // the constant term is added once, exactly
+    atomic_add_f64(ws, (double)n * (double)log2b / (double)inv_scale);
+  }
+  finish_scalar(bs, ws, nblocks, inv_scale * inv_norm, out);
+}
+
+__global__ __launch_bounds__(256) void laplace_nll_bwd_kernel(const float* xh, const float* x, const float* g, long n,
+                                                            float coef, float* dxh) {
+  const float c = g[0] * coef;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = xh[i] - x[i];
+    dxh[i] = d > 0.f ? c : (d < 0.f ? -c : 0.f);
+  }
+}
+
+// ---- log-softmax over rows of [rows][V]: one 256-thread block per row, row kept in registers --------
+// NPT = elements per thread (compile-time so the row really stays in VGPRs); V <= 256 * NPT.
+template <int NPT>
+__global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* x, float* y, int V) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float* xr = x + row * V;
+  float* yr = y + row * V;
+  float v[NPT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + k * 256;
+    v[k] = c < V ? xr[c] : -INFINITY;
+    mx = fmaxf(mx, v[k]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) se += expf(v[k] - mx);  // exp(-inf) = 0 for the padding lanes
+  se = wave_sum(se);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+  __syncthreads();
+  const float lse = mx + logf(red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + k * 256;
+    if (c < V) yr[c] = v[k] - lse;
+  }
+}
+
+template <int NPT>
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* dy, const float* y, float* dx, int V) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float* dr = dy + row * V;
+  const float* yr = y + row * V;
+  float* xr = dx + row * V;
+  float v[NPT];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + k * 256;
+    v[k] = c < V ? dr[c] : 0.f;
+    s += v[k];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int c = threadIdx.x + k * 256;
+    if (c < V) xr[c] = v[k] - expf(yr[c]) * s;
+  }
+}
+
+// ---- token NLL -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void token_nll_fwd_kernel(const float* logp, const float* ids, long rows, int V,
+                                                          float inv_norm, float* out, double* ws, int nblocks) {
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+    int t = (int)ids[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    acc += logp[r * V + t];
+  }
+  const double bs = block_sum_256(acc);
+  finish_scalar(bs, ws, nblocks, -inv_norm, out);
+}
+
+__global__ __launch_bounds__(256) void token_nll_bwd_kernel(const float* ids, const float* g, long rows, int V,
+                                                          float inv_norm, float* dlogp) {
+  const float c = -g[0] * inv_norm;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+    int t = (int)ids[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    dlogp[r * V + t] = c;
+  }
+}
+
+// ---- embedding -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* ids, const float* table, float* out, long rows,
+                                                          int V, int D) {
+  // one wave per row chunk: lanes walk the D channels
+  const long total = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / D;
+    const int d = (int)(i - r * D);
+    int t = (int)ids[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    out[i] = table[(long)t * D + d];
+  }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* ids, const float* gout, float* dtable, long rows,
+                                                          int V, int D, int padding_idx) {
+  const long total = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / D;
+    const int d = (int)(i - r * D);
+    int t = (int)ids[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    if (t != padding_idx) unsafeAtomicAdd(dtable + (long)t * D + d, gout[i]);
+  }
+}
+
+static int stream_grid(long n, int per_thread) {
+  long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+}  // namespace mopoe
+
+using namespace mopoe;
+
+extern "C" int mopoe_laplace_nll_fwd(const float* x_hat, const float* x, int64_t n, float scale, float norm, float* out,
+                                     double* ws, void* stream) {
+  if (!x_hat || !x || !out || !ws || n <= 0 || scale <= 0.f || norm <= 0.f) { set_error("laplace_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
+  const int vec = ((reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  const int nb = stream_grid(n, 16);
+  hipLaunchKernelGGL(laplace_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x_hat, x, (long)n, 1.0f / scale,
+                     logf(2.0f * scale), 1.0f / norm, out, ws, nb, vec);
+  return check_launch("laplace_nll_fwd");
+}
+
+extern "C" int mopoe_laplace_nll_bwd(const float* x_hat, const float* x, const float* g, int64_t n, float scale,
+                                     float norm, float* dx_hat, void* stream) {
+  if (!x_hat || !x || !g || !dx_hat || n <= 0) { set_error("laplace_nll_bwd: bad arguments"); return MOPOE_ERR_ARG; }
+  hipLaunchKernelGGL(laplace_nll_bwd_kernel, dim3(stream_grid(n, 8)), dim3(256), 0, (hipStream_t)stream, x_hat, x, g,
+                     (long)n, 1.0f / (scale * norm), dx_hat);
+  return check_launch("laplace_nll_bwd");
+}
+
+extern "C" int mopoe_logsoftmax_fwd(const float* x, float* y, int64_t rows, int32_t V, void* stream) {
+  if (!x || !y || rows <= 0 || V <= 0 || V > 256 * 32) { set_error("logsoftmax_fwd: bad arguments (V <= 8192)"); return MOPOE_ERR_ARG; }
+  const dim3 grid((unsigned)rows), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (V <= 256 * 4) hipLaunchKernelGGL(logsoftmax_fwd_kernel<4>, grid, blk, 0, st, x, y, V);
+  else if (V <= 256 * 16) hipLaunchKernelGGL(logsoftmax_fwd_kernel<16>, grid, blk, 0, st, x, y, V);
+  else hipLaunchKernelGGL(logsoftmax_fwd_kernel<32>, grid, blk, 0, st, x, y, V);
+  return check_launch("logsoftmax_fwd");
+}
+
+extern "C" int mopoe_logsoftmax_bwd(const float* dy, const float* y, float* dx, int64_t rows, int32_t V, void* stream) {
+  if (!dy || !y || !dx || rows <= 0 || V <= 0 || V > 256 * 32) { set_error("logsoftmax_bwd: bad arguments (V <= 8192)"); return MOPOE_ERR_ARG; }
+  const dim3 grid((unsigned)rows), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (V <= 256 * 4) hipLaunchKernelGGL(logsoftmax_bwd_kernel<4>, grid, blk, 0, st, dy, y, dx, V);
+  else if (V <= 256 * 16) hipLaunchKernelGGL(logsoftmax_bwd_kernel<16>, grid, blk, 0, st, dy, y, dx, V);
+  else hipLaunchKernelGGL(logsoftmax_bwd_kernel<32>, grid, blk, 0, st, dy, y, dx, V);
+  return check_launch("logsoftmax_bwd");
+}
+
+extern "C" int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm, float* out,
+                                   double* ws, void* stream) {
+  if (!logp || !ids || !out || !ws || rows <= 0 || V <= 0 || norm <= 0.f) { set_error("token_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
+  const int nb = stream_grid(rows, 1);
+  hipLaunchKernelGGL(token_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logp, ids, (long)rows, V,
+                     1.0f / norm, out, ws, nb);
+  return check_launch("token_nll_fwd");
+}
+
+extern "C" int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t rows, int32_t V, float norm, float* dlogp,
+                                   void* stream) {
+  if (!ids || !g || !dlogp || rows <= 0 || V <= 0) { set_error("token_nll_bwd: bad arguments"); return MOPOE_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dlogp, 0, sizeof(float) * (size_t)rows * V, st) != hipSuccess) { set_error("token_nll_bwd memset failed"); return MOPOE_ERR_LAUNCH; }
+  hipLaunchKernelGGL(token_nll_bwd_kernel, dim3(stream_grid(rows, 1)), dim3(256), 0, st, ids, g, (long)rows, V, 1.0f / norm, dlogp);
+  return check_launch("token_nll_bwd");
+}
+
+extern "C" int mopoe_embedding_fwd(const float* ids, const float* table, float* out, int64_t rows, int32_t V, int32_t D,
+                                   void* stream) {
+  if (!ids || !table || !out || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_fwd: bad arguments"); return MOPOE_ERR_ARG; }
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(stream_grid(rows * D, 4)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                     out, (long)rows, V, D);
+  return check_launch("embedding_fwd");
+}
+
+extern "C" int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int64_t rows, int32_t V, int32_t D,
+                                   int32_t padding_idx, void* stream) {
+  if (!ids || !gout || !dtable || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_bwd: bad arguments"); return MOPOE_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)V * D, st) != hipSuccess) { set_error("embedding_bwd memset failed"); return MOPOE_ERR_LAUNCH; }
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(stream_grid(rows * D, 4)), dim3(256), 0, st, ids, gout, dtable, (long)rows,
+                     V, D, padding_idx);
+  return check_launch("embedding_bwd");
+}

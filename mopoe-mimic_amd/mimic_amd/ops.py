@@ -38,7 +38,7 @@ class _Geom(C.Structure):
 
 class _BnRef(C.Structure):
     _fields_ = [("sums", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rmean", C.c_void_p),
-                ("rvar", C.c_void_p), ("inv_count", C.c_float), ("eps", C.c_float), ("C", C.c_int32),
+                ("rvar", C.c_void_p), ("inv_count", C.c_double), ("eps", C.c_float), ("C", C.c_int32),
                 ("mode", C.c_int32)]
 
 

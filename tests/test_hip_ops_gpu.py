@@ -1,0 +1,273 @@
+"""GPU parity of every HIP kernel (called through the C ABI via mimic_amd.ops) against the plain
+PyTorch fp32 emulation of the same op (tests/torch_backend.py, evaluated on the CPU).
+
+Tolerance: fp32 everywhere.  The MFMA path is an exact k-ordered fp32 fma chain; the CPU reference sums
+in a different order, so results agree to ~1e-6 relative per accumulated term:
+    |hip - ref| <= 2e-4 * max|ref| + 2e-4 * |ref|   (tensors),   1e-4 relative (double statistics).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import torch_backend as TB
+from mimic_amd import ops
+from mimic_amd.ops import Bn, Geom, Mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _log(msg):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/op_parity.log", "a") as f:
+        f.write(msg + "\n")
+
+
+def check(name, got, ref, rtol=2e-4, atol_rel=2e-4):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs()
+    bound = atol_rel * scale + rtol * ref.abs()
+    worst = (err / bound.clamp_min(1e-30)).max().item() if err.numel() else 0.0
+    _log(f"{name}: max_abs_err={err.max().item():.3e} scale={scale:.3e} worst/bound={worst:.3f}")
+    assert torch.isfinite(got).all(), name
+    assert worst <= 1.0, f"{name}: max err {err.max().item():.3e} vs scale {scale:.3e} (ratio {worst:.2f})"
+
+
+def to_dev(x):
+    if isinstance(x, torch.Tensor):
+        return x.to(DEV)
+    if isinstance(x, Bn):
+        return Bn(to_dev(x.gamma), to_dev(x.beta), x.mode, None if x.sums is None else to_dev(x.sums), x.count,
+                  None if x.rmean is None else to_dev(x.rmean), None if x.rvar is None else to_dev(x.rvar), x.eps)
+    if isinstance(x, Mask):
+        return Mask(to_dev(x.mask), x.kind, x.rows_per_sample)
+    return x
+
+
+def make_bn(c, rows, mode, gen, x=None):
+    gamma = 1 + 0.3 * torch.randn(c, generator=gen)
+    beta = 0.2 * torch.randn(c, generator=gen)
+    if mode == 1:
+        if x is None:
+            x = torch.randn(rows, c, generator=gen)
+        x2 = x.reshape(-1, c).double()
+        sums = torch.stack([x2.sum(0), (x2 * x2).sum(0)])
+        return Bn(gamma, beta, 1, sums=sums, count=x2.shape[0])
+    return Bn(gamma, beta, 2, rmean=0.1 * torch.randn(c, generator=gen), rvar=0.5 + torch.rand(c, generator=gen))
+
+
+# (name, Geom) -- every geometry family the four networks use, plus ragged / tiny-channel cases
+GEOMS = [
+    ("enc_k4s2p1_64to128", Geom(3, 8, 8, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1, False)),
+    ("enc_k4s2p1_192to256_b5", Geom(5, 4, 4, 8, 8, 192, 256, 4, 4, 2, 2, 1, 1, False)),
+    ("enc_k4s2p0_4to1", Geom(6, 1, 1, 4, 4, 320, 320, 4, 4, 2, 2, 0, 0, False)),
+    ("enc_k4s4p1_16to4", Geom(2, 4, 4, 16, 16, 64, 80, 4, 4, 4, 4, 1, 1, False)),
+    ("enc_1x1_128", Geom(2, 16, 16, 16, 16, 128, 128, 1, 1, 1, 1, 0, 0, False)),
+    ("stem_k3s2_cin1", Geom(2, 16, 16, 32, 32, 1, 64, 3, 3, 2, 2, 1, 1, False)),
+    ("linear_320to128", Geom(7, 1, 1, 1, 1, 320, 128, 1, 1, 1, 1, 0, 0, False)),
+    ("tiny_c4_k4s2p1", Geom(4, 16, 16, 32, 32, 4, 8, 4, 4, 2, 2, 1, 1, False)),
+    ("tiny_c20_k4s2p0", Geom(4, 1, 1, 4, 4, 16, 20, 4, 4, 2, 2, 0, 0, False)),
+    ("text_conv1d_k4s2p1", Geom(3, 1, 64, 1, 128, 128, 128, 1, 4, 1, 2, 0, 1, False)),
+    ("text_conv1d_to1", Geom(5, 1, 1, 1, 2, 512, 640, 1, 4, 1, 2, 0, 1, False)),
+    ("text_vocab_k1", Geom(2, 1, 128, 1, 128, 128, 3517, 1, 1, 1, 1, 0, 0, False)),
+    ("dec_k4s2p1_128to64", Geom(3, 8, 8, 16, 16, 128, 64, 4, 4, 2, 2, 1, 1, True)),
+    ("dec_k4_from1x1", Geom(5, 1, 1, 4, 4, 320, 256, 4, 4, 4, 4, 0, 0, True)),
+    ("dec_1x1", Geom(2, 8, 8, 8, 8, 192, 192, 1, 1, 1, 1, 0, 0, True)),
+    ("dec_head_k3s2p1op1_cout1", Geom(2, 16, 16, 32, 32, 64, 1, 3, 3, 2, 2, 1, 1, True)),
+    ("tiny_dec_c8_k4s2p1", Geom(4, 4, 4, 8, 8, 8, 4, 4, 4, 2, 2, 1, 1, True)),
+    ("text_convT1d_k4s2p1", Geom(3, 1, 16, 1, 32, 640, 512, 1, 4, 1, 2, 0, 1, True)),
+    ("text_convT1d_from1", Geom(4, 1, 1, 1, 4, 640, 640, 1, 4, 1, 4, 0, 0, True)),
+]
+
+
+@pytest.mark.parametrize("name,g", GEOMS, ids=[n for n, _ in GEOMS])
+def test_conv_family(name, g: Geom):
+    gen = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    x = torch.randn(g.in_shape, generator=gen)
+    wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
+    bias = 0.1 * torch.randn(g.Cout, generator=gen)
+    rows_in = x.numel() // g.Cin
+    rows_out = math.prod(g.out_shape[:3])
+    rps_out = rows_out // g.N
+    # ---- forward, plain
+    y_ref = TB.conv_fwd(x, wp, g)
+    y = ops.conv_fwd(x.to(DEV), wp.to(DEV), g)
+    check(f"{name}/fwd", y, y_ref)
+    # ---- forward with every fused option (train-mode BN, bias, channel mask, statistics)
+    for mode in (1, 2):
+        bn = make_bn(g.Cin, rows_in, mode, gen, x if mode == 1 else None)
+        cmask = Mask((torch.rand(g.N, g.Cout, generator=gen) < 0.5).float() * 2, 1, rps_out)
+        st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref)
+        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+        y = ops.conv_fwd(x.to(DEV), wp.to(DEV), g, bn_in=to_dev(bn), bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st)
+        check(f"{name}/fwd_fused_bn{mode}", y, y_ref)
+        check(f"{name}/fwd_fused_bn{mode}/stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
+    # elementwise mask
+    emask = Mask((torch.rand(g.out_shape, generator=gen) < 0.5).float() * 2, 2, rps_out)
+    y_ref = TB.conv_fwd(x, wp, g, bias=bias, mask=emask)
+    y = ops.conv_fwd(x.to(DEV), wp.to(DEV), g, bias=bias.to(DEV), mask=to_dev(emask))
+    check(f"{name}/fwd_emask", y, y_ref)
+    # ---- dgrad
+    dy = torch.randn(g.out_shape, generator=gen)
+    dx_ref = TB.conv_dgrad(dy, wp, g)
+    dx = ops.conv_dgrad(dy.to(DEV), wp.to(DEV), g)
+    check(f"{name}/dgrad", dx, dx_ref)
+    for mode in (1, 2):
+        bn = make_bn(g.Cin, rows_in, mode, gen, x if mode == 1 else None)
+        s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
+        dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
+        s = torch.zeros(2, g.Cin, dtype=torch.float64, device=DEV)
+        dx = ops.conv_dgrad(dy.to(DEV), wp.to(DEV), g, relu_bn=to_dev(bn), xin=x.to(DEV), bwd_sums=s)
+        check(f"{name}/dgrad_relubn{mode}", dx, dx_ref)
+        check(f"{name}/dgrad_relubn{mode}/sums", s, s_ref, rtol=2e-4, atol_rel=2e-4)
+    # ---- wgrad
+    dw_ref = TB.conv_wgrad(x, dy, g)
+    dw = ops.conv_wgrad(x.to(DEV), dy.to(DEV), g)
+    check(f"{name}/wgrad", dw, dw_ref)
+    bn = make_bn(g.Cin, rows_in, 1, gen, x)
+    dw_ref = TB.conv_wgrad(x, dy, g, bn_in=bn)
+    dw = ops.conv_wgrad(x.to(DEV), dy.to(DEV), g, bn_in=to_dev(bn))
+    check(f"{name}/wgrad_bn", dw, dw_ref)
+
+
+def test_conv_large_rows_splitk_and_big_tiles():
+    """shapes of the C2 config's heaviest layers at reduced batch: exercises the 128x128 tiles and the
+    split pixel reduction of wgrad."""
+    gen = torch.Generator().manual_seed(5)
+    for name, g in (("rb1", Geom(8, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False)),
+                    ("g3", Geom(8, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True))):
+        x = torch.randn(g.in_shape, generator=gen)
+        wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
+        dy = torch.randn(g.out_shape, generator=gen)
+        check(f"big/{name}/fwd", ops.conv_fwd(x.to(DEV), wp.to(DEV), g), TB.conv_fwd(x, wp, g))
+        check(f"big/{name}/dgrad", ops.conv_dgrad(dy.to(DEV), wp.to(DEV), g), TB.conv_dgrad(dy, wp, g))
+        check(f"big/{name}/wgrad", ops.conv_wgrad(x.to(DEV), dy.to(DEV), g), TB.conv_wgrad(x, dy, g), rtol=5e-4,
+              atol_rel=5e-4)
+
+
+@pytest.mark.parametrize("rows,c", [(4096, 128), (1000, 192), (37, 20), (5, 640), (3000, 1), (64, 3517 // 7 * 4)])
+def test_block_glue(rows, c):
+    gen = torch.Generator().manual_seed(rows + c)
+    s, m, g = (torch.randn(rows, c, generator=gen) for _ in range(3))
+    n = 1 if rows < 8 else 4
+    rps = rows // n
+    rows = n * rps
+    s, m, g = s[:rows].contiguous(), m[:rows].contiguous(), g[:rows].contiguous()
+    for mode in (1, 2):
+        bn = make_bn(c, rows, mode, gen, s if mode == 1 else None)
+        st_ref = torch.zeros(2, c, dtype=torch.float64)
+        out_ref = TB.block_out_fwd(s, m, bn, out_stats=st_ref)
+        st = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+        out = ops.block_out_fwd(s.to(DEV), m.to(DEV), to_dev(bn), out_stats=st)
+        check(f"block_out_fwd[{rows}x{c}]bn{mode}", out, out_ref)
+        check(f"block_out_fwd[{rows}x{c}]bn{mode}/stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
+        sums_ref = TB.bn_bwd_reduce(g, s, bn)
+        sums = ops.bn_bwd_reduce(g.to(DEV), s.to(DEV), to_dev(bn))
+        check(f"bn_bwd_reduce[{rows}x{c}]bn{mode}", sums, sums_ref, rtol=2e-4, atol_rel=2e-4)
+        for mask in (None, Mask((torch.rand(n, c, generator=gen) < 0.5).float() * 2, 1, rps),
+                     Mask((torch.rand(rows, c, generator=gen) < 0.5).float() * 2, 2, rps)):
+            tag = f"[{rows}x{c}]bn{mode}mask{0 if mask is None else mask.kind}"
+            ref = TB.block_out_bwd(g, s, bn, sums_ref, mask, want_colsum_dm=True, want_colsum_ds=True)
+            got = ops.block_out_bwd(g.to(DEV), s.to(DEV), to_dev(bn), sums_ref.to(DEV), to_dev(mask),
+                                    want_colsum_dm=True, want_colsum_ds=True)
+            for nm, a, b in zip(("dm", "ds", "dgamma", "dbeta", "colsum_dm"), got, ref):
+                check(f"block_out_bwd{tag}/{nm}", a, b)
+            # colsum of ds is analytically ~0 in train mode: compare on the scale of ds's column L1 norms
+            scale = ref[1].abs().sum(0).max().item()
+            assert (got[5].cpu() - ref[5]).abs().max().item() <= 2e-5 * scale + 1e-6
+            ref = TB.bn_bwd_apply(g, s, bn, sums_ref, mask=mask, add=m, want_colsum=True)
+            got = ops.bn_bwd_apply(g.to(DEV), s.to(DEV), to_dev(bn), sums_ref.to(DEV), mask=to_dev(mask),
+                                   add=m.to(DEV), want_colsum=True)
+            for nm, a, b in zip(("dx", "dgamma", "dbeta"), got, ref):
+                check(f"bn_bwd_apply{tag}/{nm}", a, b)
+            scale = ref[0].abs().sum(0).max().item()
+            assert (got[3].cpu() - ref[3]).abs().max().item() <= 2e-5 * scale + 1e-6
+    check(f"colsum[{rows}x{c}]", ops.colsum(s.to(DEV)), TB.colsum(s), rtol=1e-4, atol_rel=1e-4 * math.sqrt(rows))
+
+
+def test_bn_running_update():
+    gen = torch.Generator().manual_seed(3)
+    entries_ref, entries = [], []
+    for c, rows in ((64, 1000), (20, 7), (640, 64)):
+        x = torch.randn(rows, c, generator=gen).double() * 2 + 1
+        sums = torch.stack([x.sum(0), (x * x).sum(0)])
+        rm, rv = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+        entries_ref.append((sums, rm.clone(), rv.clone(), rows))
+        entries.append((sums.to(DEV), rm.to(DEV), rv.to(DEV), rows))
+    TB.bn_running_update(entries_ref)
+    keep = ops.bn_running_update(entries)
+    torch.cuda.synchronize()
+    for (_, rm_r, rv_r, _), (_, rm, rv, _) in zip(entries_ref, entries):
+        check("running_mean", rm, rm_r, 1e-5, 1e-5)
+        check("running_var", rv, rv_r, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("present", [(1, 1, 1), (1, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)])
+@pytest.mark.parametrize("b,d", [(64, 128), (7, 8), (65, 64)])
+def test_latent(present, b, d):
+    from mimic_amd.mmvae import kl_weights, mixture_row_starts
+    gen = torch.Generator().manual_seed(b * 100 + d + sum(present))
+    mu = [torch.randn(b, d, generator=gen) if p else None for p in present]
+    lv = [0.5 * torch.randn(b, d, generator=gen) if p else None for p in present]
+    eps = torch.randn(b, d, generator=gen)
+    k = len(TB._active_subsets(mu))
+    rs, w, norm = mixture_row_starts(b, k), kl_weights(k), float(b + 3)
+    ref = TB.latent_fwd(mu, lv, eps, rs, w, norm)
+    got = ops.latent_fwd([to_dev(t) for t in mu], [to_dev(t) for t in lv], eps.to(DEV), rs, w, norm)
+    for nm, a, r in zip(("mus", "lvs", "jm", "jl", "z", "klds", "jd"), got, ref):
+        check(f"latent_fwd{present}[{b}x{d}]/{nm}", a, r, 1e-4, 1e-5)
+    # second call must see a clean workspace
+    got2 = ops.latent_fwd([to_dev(t) for t in mu], [to_dev(t) for t in lv], eps.to(DEV), rs, w, norm)
+    check("latent_fwd/rerun/klds", got2[5], ref[5], 1e-4, 1e-5)
+    gs = [torch.randn(t.shape, generator=gen) for t in ref]
+    for combo in ("all", "train"):  # 'train': only z and joint_divergence carry gradient
+        g_use = gs if combo == "all" else [None, None, None, None, gs[4], None, gs[6]]
+        dmu_r, dlv_r = TB.latent_bwd(mu, lv, eps, rs, w, norm, *g_use)
+        dmu, dlv = ops.latent_bwd([to_dev(t) for t in mu], [to_dev(t) for t in lv], eps.to(DEV), rs, w, norm,
+                                  *[to_dev(t) for t in g_use])
+        for s in range(3):
+            if present[s]:
+                check(f"latent_bwd{present}[{b}x{d}]{combo}/dmu{s}", dmu[s], dmu_r[s], 2e-4, 2e-5)
+                check(f"latent_bwd{present}[{b}x{d}]{combo}/dlv{s}", dlv[s], dlv_r[s], 2e-4, 2e-5)
+
+
+def test_likelihoods_and_embedding():
+    gen = torch.Generator().manual_seed(11)
+    for n in (64 * 128 * 128, 4099, 17):
+        xh, x = torch.randn(n, generator=gen), torch.rand(n, generator=gen)
+        ref = TB.laplace_nll_fwd(xh, x, 0.75, 64.0)
+        got = ops.laplace_nll_fwd(xh.to(DEV), x.to(DEV), 0.75, 64.0)
+        check(f"laplace_fwd[{n}]", got, ref, 2e-6, 2e-6)
+        got = ops.laplace_nll_fwd(xh.to(DEV), x.to(DEV), 0.75, 64.0)  # workspace left clean
+        check(f"laplace_fwd[{n}]/rerun", got, ref, 2e-6, 2e-6)
+        g = torch.tensor([0.33])
+        check(f"laplace_bwd[{n}]", ops.laplace_nll_bwd(xh.to(DEV), x.to(DEV), g.to(DEV), 0.75, 64.0),
+              TB.laplace_nll_bwd(xh, x, g, 0.75, 64.0), 1e-6, 1e-6)
+    for rows, v in ((8 * 128, 3517), (33, 50), (5, 1024), (3, 7000)):
+        x = 3 * torch.randn(rows, v, generator=gen)
+        y_ref = TB.logsoftmax_fwd(x)
+        y = ops.logsoftmax_fwd(x.to(DEV))
+        check(f"logsoftmax_fwd[{rows}x{v}]", y, y_ref, 1e-5, 1e-6)
+        dy = torch.randn(rows, v, generator=gen)
+        check(f"logsoftmax_bwd[{rows}x{v}]", ops.logsoftmax_bwd(dy.to(DEV), y), TB.logsoftmax_bwd(dy, y_ref), 1e-4, 1e-5)
+        ids = torch.randint(0, v, (rows,), generator=gen).float()
+        check(f"token_nll_fwd[{rows}x{v}]", ops.token_nll_fwd(y, ids.to(DEV), 8.0), TB.token_nll_fwd(y_ref, ids, 8.0),
+              2e-6, 2e-6)
+        g = torch.tensor([0.7])
+        check(f"token_nll_bwd[{rows}x{v}]", ops.token_nll_bwd(ids.to(DEV), g.to(DEV), (rows, v), 8.0),
+              TB.token_nll_bwd(ids, g, (rows, v), 8.0), 1e-6, 1e-6)
+    for v, d, shape in ((3517, 128, (8, 128)), (50, 4, (4, 128))):
+        table = torch.randn(v, d, generator=gen)
+        ids = torch.randint(0, v, shape, generator=gen).float()
+        ids[:, :3] = 0
+        check(f"embedding_fwd[{v}x{d}]", ops.embedding_fwd(ids.to(DEV), table.to(DEV)), TB.embedding_fwd(ids, table), 0, 0)
+        gout = torch.randn(*shape, d, generator=gen)
+        check(f"embedding_bwd[{v}x{d}]", ops.embedding_bwd(ids.to(DEV), gout.to(DEV), v, 0),
+              TB.embedding_bwd(ids, gout, v, 0), 1e-4, 1e-5)
