@@ -56,8 +56,7 @@ def _mask_mult(y, mask: Mask):
     if mask is None:
         return None
     if mask.kind == 1:
-        n = mask.mask.shape[0]
-        return mask.mask.view(n, *([1] * (y.dim() - 2)), y.shape[-1])
+        return mask.mask.repeat_interleave(mask.rows_per_sample, dim=0).view(y.shape)
     return mask.mask.view(y.shape)
 
 
