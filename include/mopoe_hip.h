@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 1
+#define MOPOE_ABI_VERSION 2
 
 /* error codes */
 #define MOPOE_OK 0
@@ -85,16 +85,22 @@ typedef struct {
  *
  * y = mask * (conv(act(x)) + bias), act(x) = relu(bn(x)) when bn_in.mode != 0 (the BN -> ReLU that
  * precedes every conv inside a residual block is fused into the operand load).
- * out_stats (optional) += {sum, sumsq} of the stored y per output channel. */
+ * out_stats (optional) += {sum, sumsq} of the stored y per output channel.
+ *
+ * workspace: caller-owned scratch (mopoe_conv_workspace_bytes() is the recommended size; may be NULL/0).
+ * Layers whose output grid cannot fill the chip split the tap x channel reduction across blocks, park
+ * the partial sums there and finish (bias, mask, statistics) in a second small kernel. */
+size_t mopoe_conv_workspace_bytes(void);
 int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y,
                    const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
-                   double* out_stats, void* stream);
+                   double* out_stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dx = d(conv)/d(input) applied to dy.  If relu_bn.mode != 0 the ReLU that fed the conv is inverted in
  * the epilogue, dx *= [bn(xin) > 0], and bwd_sums (optional) += {sum dx, sum dx*xhat} per input channel
  * (the two reductions BatchNorm's backward needs), xhat = (xin - mean) * rstd. */
 int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
-                     const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* stream);
+                     const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* dwp[kh*kw][Cin][Cout] = d(conv)/d(weight); x is transformed by relu(bn(x)) when bn_in.mode != 0.
  * dwp is overwritten (the library zero-fills it first when it splits the pixel reduction). */
@@ -207,8 +213,11 @@ int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int6
 
 /* ---- profiling support for bench.py ------------------------------------------------------------------
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
- * stream.  mopoe_prof_collect synchronises those events and returns the number of launches, their
- * summed duration (ms) and their summed algorithmic FLOPs since the last collect. */
+ * stream.  mopoe_prof_collect synchronises those events and fills, per kernel kind
+ * (0 gather_gemm<128,128>, 1 gather_gemm<64,64>, 2 wgrad_gemm<128,128>, 3 wgrad_gemm<64,64>,
+ * 4 gather_gemm<256,64>; arrays of MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms) and their
+ * summed algorithmic FLOPs since the last collect. */
+#define MOPOE_PROF_KINDS 5
 int mopoe_prof_enable(int32_t on);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

@@ -32,30 +32,33 @@ int check_launch(const char* what) {
 struct ProfRec {
   hipEvent_t start, stop;
   double flops;
+  int kind;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_pool;   // created lazily, reused
 static size_t g_prof_used = 0;
 
-ProfScope::ProfScope(hipStream_t s, double flops) : stream(s), slot(-1) {
+ProfScope::ProfScope(hipStream_t s, double flops, int kind) : stream(s), slot(-1) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_used == g_prof_pool.size()) {
     ProfRec r;
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
     r.flops = 0;
+    r.kind = 0;
     g_prof_pool.push_back(r);
   }
   slot = (int)g_prof_used++;
   g_prof_pool[slot].flops = flops;
-  hipEventRecord(g_prof_pool[slot].start, stream);
+  g_prof_pool[slot].kind = kind;
+  (void)hipEventRecord(g_prof_pool[slot].start, stream);
 }
 
 ProfScope::~ProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEventRecord(g_prof_pool[slot].stop, stream);
+  (void)hipEventRecord(g_prof_pool[slot].stop, stream);
 }
 
 }  // namespace mopoe
@@ -75,17 +78,16 @@ extern "C" int mopoe_prof_enable(int32_t on) {
 
 extern "C" int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms = 0, fl = 0;
+  for (int k = 0; k < PROF_NKINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_flops[k] = 0; }
   for (size_t i = 0; i < g_prof_used; ++i) {
     if (hipEventSynchronize(g_prof_pool[i].stop) != hipSuccess) { set_error("prof_collect: event sync failed"); return MOPOE_ERR_LAUNCH; }
     float t = 0;
     if (hipEventElapsedTime(&t, g_prof_pool[i].start, g_prof_pool[i].stop) != hipSuccess) { set_error("prof_collect: elapsed failed"); return MOPOE_ERR_LAUNCH; }
-    ms += t;
-    fl += g_prof_pool[i].flops;
+    const int k = g_prof_pool[i].kind;
+    launches[k] += 1;
+    total_ms[k] += t;
+    total_flops[k] += g_prof_pool[i].flops;
   }
-  if (launches) *launches = (int64_t)g_prof_used;
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = fl;
   g_prof_used = 0;
   return MOPOE_OK;
 }

@@ -15,9 +15,18 @@
 // ([k][m], [k][n]) so that every MFMA operand read is a conflict-free ds_read_b32 of consecutive
 // lanes.  BatchNorm+ReLU of the operand, bias, dropout mask, BN statistics and the ReLU/BN backward
 // reductions are fused into the operand load / epilogue (see include/mopoe_hip.h).
+#include <algorithm>
+#include <initializer_list>
+
 #include "common.hpp"
 
 namespace mopoe {
+
+// edge.hip: streaming kernels for the single-channel image-side layers
+bool edge_supported(const mopoe_conv_geom* g, int C, std::initializer_list<const void*> ptrs);
+int edge_expand(const float* scal, const float* W, float* out, const mopoe_conv_geom* g, int C, double* stats, hipStream_t st);
+int edge_wgrad(const float* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st);
+int edge_reduce(const float* x, const float* W, const float* bias, float* out, const mopoe_conv_geom* g, int C, hipStream_t st);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -42,6 +51,9 @@ struct GemmArgs {
   mopoe_bn_ref relu_bn;
   const float* xin;
   double* bwd_sums;
+  int nsplit;            // split-K factor (1 = none)
+  float* partial;        // split-K: [nsplit][rows_total][Cn] raw partial sums (else nullptr)
+  long rows_total;       // N*Hy*Wy
 };
 
 __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
@@ -58,9 +70,12 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
   return v;
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GemmArgs a) {
-  constexpr int WM = BM / 2, WN = BN / 2;         // wave tile
+// Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
+// (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
   constexpr int TI = WM / 32, TJ = WN / 32;       // MFMA tiles per wave
   constexpr int A_LD = BM + LDS_PAD, B_LD = BN + LDS_PAD;
   constexpr int A_PER_THR = BM / 64;              // float4 loads per thread for the A tile
@@ -68,15 +83,15 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GemmArgs a) {
 
   __shared__ __attribute__((aligned(16))) float As[2][BK][A_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][B_LD];
-  __shared__ float bnS[MAX_BN_C];
-  __shared__ float bnT[MAX_BN_C];
+  __shared__ __attribute__((aligned(16))) float bnS[MAX_BN_C];
+  __shared__ __attribute__((aligned(16))) float bnT[MAX_BN_C];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.x * BM;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int n0 = blockIdx.y * BN;
-  const int phase = blockIdx.z;
+  const int phase = blockIdx.z / a.nsplit;
+  const int split = blockIdx.z - phase * a.nsplit;
 
   // ---- phase / tap enumeration ---------------------------------------------------------------
   int nty, ntx, ky0, kx0, kstep_y, kstep_x, dsgn, cy = 0, cx = 0, phy = 0, phx = 0;
@@ -91,203 +106,271 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GemmArgs a) {
     cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
   }
   const int nkc = (a.Ck + BK - 1) / BK;
-  const int total = nty * ntx * nkc;
+  const int total_all = nty * ntx * nkc;
+  // split-K: this block reduces iterations [it_beg, it_end) of the flattened (tap, k-chunk) space
+  const int per_split = (total_all + a.nsplit - 1) / a.nsplit;
+  const int it_beg = split * per_split;
+  const int it_end = it_beg + per_split < total_all ? it_beg + per_split : total_all;
+  const int total = it_end > it_beg ? it_end - it_beg : 0;
 
   // ---- BN(+ReLU) table for the operand transform -----------------------------------------------
   const bool xform = a.bn_in.mode != 0;
   if (xform) {
-    for (int c = tid; c < a.Ck; c += 256) {
-      const BnC k = bn_coef(a.bn_in, c);
+    for (int c = tid; c < ((a.Ck + 3) & ~3); c += 256) {
+      BnC k = BnC{0.f, 0.f, 0.f, 0.f};
+      if (c < a.Ck) k = bn_coef(a.bn_in, c);
       bnS[c] = k.scale;
       bnT[c] = k.shift;
     }
-  }
-
-  // ---- per-thread A rows ---------------------------------------------------------------------------
-  const int kq = tid & 3;
-  int rn[A_PER_THR], ry0[A_PER_THR], rx0[A_PER_THR];
-  bool rvalid[A_PER_THR];
-#pragma unroll
-  for (int i = 0; i < A_PER_THR; ++i) {
-    const long m = m0 + (tid >> 2) + i * 64;
-    rvalid[i] = m < a.rows_per_phase;
-    const long mm = rvalid[i] ? m : 0;
-    const int hw = a.Hq * a.Wq;
-    const int n = (int)(mm / hw);
-    const int rem = (int)(mm - (long)n * hw);
-    const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
-    rn[i] = n;
-    if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
-    else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
-  }
-
-  float4 ra[A_PER_THR], rb[B_PER_THR];
-
-  auto load_tiles = [&](int it) {
-    const int tap = it / nkc;
-    const int kc = (it - tap * nkc) * BK;
-    const int jy = tap / ntx, jx = tap - jy * ntx;
-    const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
-    // A: gathered activation rows
-    const int ck = kc + kq * 4;
-    const int nvk = a.Ck - ck;
-#pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) {
-      const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
-      const bool ok = rvalid[i] && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && nvk > 0;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const long row = ((long)rn[i] * a.Hx + iy) * a.Wx + ix;
-        v = ld4(a.X + row * a.Ck + ck, nvk, a.vecA);
-        if (xform) {
-          v.x = fmaxf(fmaf(v.x, bnS[ck], bnT[ck]), 0.f);
-          if (nvk > 1) v.y = fmaxf(fmaf(v.y, bnS[ck + 1], bnT[ck + 1]), 0.f);
-          if (nvk > 2) v.z = fmaxf(fmaf(v.z, bnS[ck + 2], bnT[ck + 2]), 0.f);
-          if (nvk > 3) v.w = fmaxf(fmaf(v.w, bnS[ck + 3], bnT[ck + 3]), 0.f);
-        }
-      }
-      ra[i] = v;
-    }
-    // B: weights
-    if (a.w_nk == 0) {
-      // W[(wtap*Cin_w + k)*Cout_w + n], n contiguous; tile rows = k
-      constexpr int N4 = BN / 4;  // float4 per k-row
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int k = tid / N4 + i * (256 / N4);
-        const int n = n0 + (tid % N4) * 4;
-        const int kk = kc + k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < a.Ck && n < a.Cn)
-          v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, a.vecB);
-        rb[i] = v;
-      }
-    } else {
-      // W[(wtap*Cin_w + n)*Cout_w + k], k contiguous; tile rows = n
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int n = n0 + (tid >> 2) + i * 64;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < a.Cn && nvk > 0)
-          v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, a.vecB);
-        rb[i] = v;
-      }
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) {
-      const int r = (tid >> 2) + i * 64;
-      As[buf][kq * 4 + 0][r] = ra[i].x;
-      As[buf][kq * 4 + 1][r] = ra[i].y;
-      As[buf][kq * 4 + 2][r] = ra[i].z;
-      As[buf][kq * 4 + 3][r] = ra[i].w;
-    }
-    if (a.w_nk == 0) {
-      constexpr int N4 = BN / 4;
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int k = tid / N4 + i * (256 / N4);
-        *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int r = (tid >> 2) + i * 64;
-        Bs[buf][kq * 4 + 0][r] = rb[i].x;
-        Bs[buf][kq * 4 + 1][r] = rb[i].y;
-        Bs[buf][kq * 4 + 2][r] = rb[i].z;
-        Bs[buf][kq * 4 + 3][r] = rb[i].w;
-      }
-    }
-  };
-
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (xform) __syncthreads();  // bnS/bnT visible before the first transform
-  if (total > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  const int l31 = lane & 31, lhi = lane >> 5;
-  for (int it = 0; it < total; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < total) load_tiles(it + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + lhi;
-      float av[TI], bv[TJ];
-#pragma unroll
-      for (int i = 0; i < TI; ++i) av[i] = As[cur][k][wm * WM + i * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) bv[j] = Bs[cur][k][wn * WN + j * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    if (it + 1 < total) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------------
+  const int kq = tid & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
   const bool do_relu_bn = a.relu_bn.mode != 0;
+  const int hw = a.Hq * a.Wq;
+
+  // per-column epilogue constants and running column sums (persist across this block's M tiles)
+  float cbias[TJ], s1[TJ], s2[TJ];
+  BnC rbc[TJ];
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int n = n0 + wn * WN + j * 32 + l31;
-    const bool nok = n < a.Cn;
-    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
-    BnC rb_c = {0.f, 0.f, 0.f, 0.f};
-    if (nok && do_relu_bn) rb_c = bn_coef(a.relu_bn, n);
-    float s1 = 0.f, s2 = 0.f;
+    s1[j] = s2[j] = 0.f;
+    cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
+    rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
+    if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+  }
+
+  const long nMt = (a.rows_per_phase + BM - 1) / BM;
+  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+    const long m0 = mt * BM;
+
+    // ---- per-thread A rows -------------------------------------------------------------------------
+    int rn[A_PER_THR], ry0[A_PER_THR], rx0[A_PER_THR];
+    bool rvalid[A_PER_THR];
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const long m = m0 + (tid >> 2) + i * 64;
+      rvalid[i] = m < a.rows_per_phase;
+      const unsigned mm = rvalid[i] ? (unsigned)m : 0u;   // rows_per_phase < 2^31 (checked on the host)
+      const int n = (int)(mm / (unsigned)hw);
+      const int rem = (int)(mm - (unsigned)n * (unsigned)hw);
+      const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
+      rn[i] = n;
+      if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
+      else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
+    }
+
+    float4 ra[A_PER_THR], rb[B_PER_THR];
+
+    auto load_tiles = [&](int it) {
+      const int tap = it / nkc;
+      const int kc = (it - tap * nkc) * BK;
+      const int jy = tap / ntx, jx = tap - jy * ntx;
+      const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+      const int ck = kc + kq * 4;
+      const int nvk = a.Ck - ck;
+      float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+      if (xform && nvk > 0) {
+        sc4 = *reinterpret_cast<const float4*>(&bnS[ck]);
+        sh4 = *reinterpret_cast<const float4*>(&bnT[ck]);
+      }
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) {
+        const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
+        const bool ok = rvalid[i] && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && nvk > 0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          const long row = ((long)rn[i] * a.Hx + iy) * a.Wx + ix;
+          v = ld4(a.X + row * a.Ck + ck, nvk, a.vecA);
+          if (xform) {
+            // table entries past Ck are zero, and so are the operand lanes past Ck (ld4): relu(0*0+0) = 0
+            v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
+            v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
+            v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+          }
+        }
+        ra[i] = v;
+      }
+      if (a.w_nk == 0) {
+        constexpr int N4 = BN / 4;  // float4 per k-row
+#pragma unroll
+        for (int i = 0; i < B_PER_THR; ++i) {
+          const int k = tid / N4 + i * (256 / N4);
+          const int n = n0 + (tid % N4) * 4;
+          const int kk = kc + k;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kk < a.Ck && n < a.Cn)
+            v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, a.vecB);
+          rb[i] = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_PER_THR; ++i) {
+          const int n = n0 + (tid >> 2) + i * 64;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n < a.Cn && nvk > 0)
+            v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, a.vecB);
+          rb[i] = v;
+        }
+      }
+    };
+
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) {
+        const int r = (tid >> 2) + i * 64;
+        As[buf][kq * 4 + 0][r] = ra[i].x;
+        As[buf][kq * 4 + 1][r] = ra[i].y;
+        As[buf][kq * 4 + 2][r] = ra[i].z;
+        As[buf][kq * 4 + 3][r] = ra[i].w;
+      }
+      if (a.w_nk == 0) {
+        constexpr int N4 = BN / 4;
+#pragma unroll
+        for (int i = 0; i < B_PER_THR; ++i) {
+          const int k = tid / N4 + i * (256 / N4);
+          *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_PER_THR; ++i) {
+          const int r = (tid >> 2) + i * 64;
+          Bs[buf][kq * 4 + 0][r] = rb[i].x;
+          Bs[buf][kq * 4 + 1][r] = rb[i].y;
+          Bs[buf][kq * 4 + 2][r] = rb[i].z;
+          Bs[buf][kq * 4 + 3][r] = rb[i].w;
+        }
+      }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (total > 0) {
+      load_tiles(it_beg);
+      store_tiles(0);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < total; ++it) {
+      const int cur = it & 1;
+      if (it + 1 < total) load_tiles(it_beg + it + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int k = kk * 2 + lhi;
+        float av[TI], bv[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) av[i] = As[cur][k][wm * WM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bv[j] = Bs[cur][k][wn * WN + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      if (it + 1 < total) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue of this M tile ------------------------------------------------------------------------
+    const float* __restrict__ xin = a.xin;
+    float* __restrict__ Yp = a.Y;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (!nok || m >= a.rows_per_phase) continue;
-        long yrow;
-        if (a.form == 0) {
-          yrow = m;
-        } else {
-          const int hw = a.Hq * a.Wq;
-          const int nn = (int)(m / hw);
-          const int rem = (int)(m - (long)nn * hw);
-          const int py = rem / a.Wq, px = rem - py * a.Wq;
-          yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+      for (int rg = 0; rg < 4; ++rg) {
+        // four consecutive rows per group: issue their independent loads first, then the dependent math
+        long yrows[4];
+        const float* mrows[4];
+        float xv[4][TJ];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const long m = m0 + wm * WM + i * 32 + r4 + 8 * rg + 4 * lhi;
+          yrows[r4] = -1;
+          mrows[r4] = nullptr;
+          if (m < a.rows_per_phase) {
+            // 32-bit index arithmetic (64-bit integer division costs hundreds of cycles per element)
+            const unsigned mu = (unsigned)m;
+            const unsigned nn = mu / (unsigned)hw;
+            if (a.form == 0) {
+              yrows[r4] = m;
+            } else {
+              const unsigned rem = mu - nn * (unsigned)hw;
+              const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
+              yrows[r4] = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+            }
+            if (a.mask.kind == 1) mrows[r4] = a.mask.mask + (long)nn * a.Cn;
+            else if (a.mask.kind == 2) mrows[r4] = a.mask.mask + yrows[r4] * a.Cn;
+          }
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            xv[r4][j] = 0.f;
+            if (do_relu_bn && !a.partial && yrows[r4] >= 0 && n < a.Cn) xv[r4][j] = xin[yrows[r4] * a.Cn + n];
+          }
         }
-        float v = acc[i][j][r] + bias;
-        if (a.mask.kind != 0) v *= mask_at(a.mask, yrow, n, a.Cn);
-        if (do_relu_bn) {
-          const float xi = a.xin[yrow * a.Cn + n];
-          v = (fmaf(xi, rb_c.scale, rb_c.shift) > 0.f) ? v : 0.f;
-          s1 += v;
-          s2 += v * ((xi - rb_c.mean) * rb_c.rstd);
-        } else {
-          s1 += v;
-          s2 += v * v;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const long yrow = yrows[r4];
+          if (yrow < 0) continue;
+          const int r = rg * 4 + r4;
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+            if (n >= a.Cn) continue;
+            if (a.partial) {  // split-K: raw partial sums, reduced by splitk_epilogue_kernel
+              a.partial[((long)split * a.rows_total + yrow) * a.Cn + n] = acc[i][j][r];
+              continue;
+            }
+            float v = acc[i][j][r] + cbias[j];
+            if (mrows[r4]) v *= mrows[r4][n];
+            if (do_relu_bn) {
+              const float xi = xv[r4][j];
+              v = (fmaf(xi, rbc[j].scale, rbc[j].shift) > 0.f) ? v : 0.f;
+              s1[j] += v;
+              s2[j] += v * ((xi - rbc[j].mean) * rbc[j].rstd);
+            } else {
+              s1[j] += v;
+              s2[j] += v * v;
+            }
+            Yp[yrow * a.Cn + n] = v;
+          }
         }
-        a.Y[yrow * a.Cn + n] = v;
       }
     }
-    double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
-    if (sums) {
+  }
+
+  // ---- column statistics: one atomic per column per block ------------------------------------------------
+  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
+  if (sums && !a.partial) {
+    __shared__ float cs[2][4][64];  // [stat][wave][column within the wave tile (<= 64)]
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
       // lanes l and l+32 hold the same column
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (nok && lhi == 0) {
-        atomic_add_f64(sums + n, (double)s1);
-        atomic_add_f64(sums + a.Cn + n, (double)s2);
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lhi == 0) { cs[0][wave][j * 32 + l31] = t1; cs[1][wave][j * 32 + l31] = t2; }
+    }
+    __syncthreads();
+    // waves with the same wn own the same columns: combine them, then one atomic per column
+    for (int c = tid; c < BN; c += 256) {
+      const int wnc = c / WN, cc = c - wnc * WN;
+      const int n = n0 + c;
+      if (n < a.Cn) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) { t1 += cs[0][w * WGN + wnc][cc]; t2 += cs[1][w * WGN + wnc][cc]; }
+        atomic_add_f64(sums + n, (double)t1);
+        atomic_add_f64(sums + a.Cn + n, (double)t2);
       }
     }
   }
@@ -488,11 +571,61 @@ static int validate_geom(const mopoe_conv_geom* g) {
   return 0;
 }
 
+// ---- split-K epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums ------
+// block = 64 columns x 4 rows, ONE output element per thread; the nsplit partials are summed with 8
+// independent loads in flight per thread.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs a) {
+  __shared__ float cs[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const long row = (long)blockIdx.y * 4 + ty;
+  const bool ok = n < a.Cn && row < a.rows_total;
+  const bool do_relu_bn = a.relu_bn.mode != 0;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    const long stride = a.rows_total * (long)a.Cn;
+    const float* p = a.partial + row * a.Cn + n;
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= a.nsplit; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] += p[(long)(s + u) * stride];
+    }
+    for (; s < a.nsplit; ++s) acc8[0] += p[(long)s * stride];
+    float v = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    if (a.bias) v += a.bias[n];
+    if (a.mask.kind != 0) v *= mask_at(a.mask, row, n, a.Cn);
+    if (do_relu_bn) {
+      const BnC rb = bn_coef(a.relu_bn, n);
+      const float xi = a.xin[row * a.Cn + n];
+      v = (fmaf(xi, rb.scale, rb.shift) > 0.f) ? v : 0.f;
+      s1 = v;
+      s2 = v * ((xi - rb.mean) * rb.rstd);
+    } else {
+      s1 = v;
+      s2 = v * v;
+    }
+    a.Y[row * a.Cn + n] = v;
+  }
+  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
+  if (sums) {
+    cs[0][ty][tx] = s1;
+    cs[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && n < a.Cn) {
+      atomic_add_f64(sums + n, (double)((cs[0][0][tx] + cs[0][1][tx]) + (cs[0][2][tx] + cs[0][3][tx])));
+      atomic_add_f64(sums + a.Cn + n, (double)((cs[1][0][tx] + cs[1][1][tx]) + (cs[1][2][tx] + cs[1][3][tx])));
+    }
+  }
+}
+
+constexpr size_t WS_RECOMMENDED = 64u << 20;
+
 // dest_on_small: 1 -> form 0 (Y on the small grid), 0 -> form 1 (Y on the big grid)
 static int launch_gather(const float* X, const float* W, const float* bias, float* Y, const mopoe_conv_geom* g,
                          int dest_on_small, int Ck, int Cn, int w_nk, const mopoe_bn_ref* bn_in,
                          const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
-                         const float* xin, double* bwd_sums, hipStream_t stream) {
+                         const float* xin, double* bwd_sums, void* ws, size_t ws_bytes, hipStream_t stream) {
   GemmArgs a;
   a.X = X; a.W = W; a.Y = Y; a.bias = bias;
   a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;
@@ -506,6 +639,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     nphase = g->sh * g->sw;
   }
   a.rows_per_phase = (long)g->N * a.Hq * a.Wq;
+  a.rows_total = (long)g->N * a.Hy * a.Wy;
   a.vecA = (Ck % 4 == 0) && aligned16(X);
   a.vecB = (g->Cout % 4 == 0) && aligned16(W);
   mopoe_bn_ref none = {};
@@ -515,47 +649,86 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.out_stats = out_stats;
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
+  a.nsplit = 1; a.partial = nullptr;
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
   if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
   if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
+  if (a.mask.kind == 1 && a.mask.rows_per_sample != a.Hy * a.Wy) { set_error("channel mask: rows_per_sample must be Hout*Wout"); return MOPOE_ERR_ARG; }
+  if (a.rows_total >= (1L << 31)) { set_error("conv: more than 2^31 output rows"); return MOPOE_ERR_ARG; }
 
-  // tile choice: big tiles when they still fill the chip, else 64x64
-  const long tiles128 = (long)ceil_div(a.rows_per_phase, 128) * ceil_div(Cn, 128) * nphase;
-  const bool big = tiles128 >= 192 && Cn > 64;
+  // ---- tile choice -------------------------------------------------------------------------------------------
+  // 0: 128x128 (2x2 waves)   1: 256x64 (4x1 waves; narrow outputs, many rows)   2: 64x64 (2x2 waves)
+  // Wide outputs always take the 128x128 tile (best operand reuse); when that leaves the chip under-filled the
+  // tap x channel reduction is split across blocks instead of shrinking the tile.
+  int cfg;
+  if (Cn > 64) cfg = (a.rows_per_phase > 64 || Cn >= 256) ? 0 : 2;
+  else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
+  const int bm = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64), bn = cfg == 0 ? 128 : 64;
+  const long nMt = ceil_div(a.rows_per_phase, bm);
+  const int nNt = ceil_div(Cn, bn);
+  // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
+  const int nkc = ceil_div(Ck, BK);
+  const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
+  const long blocks = nMt * nNt * nphase;
+  if (ws && blocks < 160 && iters >= 16) {
+    long ns = std::min<long>((384 + blocks - 1) / blocks, iters / 8);
+    const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
+    if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
+    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
+  }
+  // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
+  long gx = std::min<long>(nMt, std::max<long>(1, 768 / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
-  ProfScope prof(stream, flops);
-  if (big) {
-    dim3 grid(ceil_div(a.rows_per_phase, 128), ceil_div(Cn, 128), nphase);
-    hipLaunchKernelGGL((gather_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
-  } else {
-    dim3 grid(ceil_div(a.rows_per_phase, 64), ceil_div(Cn, 64), nphase);
-    hipLaunchKernelGGL((gather_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+  {
+    ProfScope prof(stream, flops, cfg == 0 ? PROF_GATHER128 : (cfg == 1 ? PROF_GATHER256x64 : PROF_GATHER64));
+    dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
+    if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a);
+    else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, stream, a);
+    if (int rc = check_launch("gather_gemm")) return rc;
+    if (a.partial) {
+      dim3 eg(ceil_div(Cn, 64), ceil_div(a.rows_total, 4));
+      hipLaunchKernelGGL(splitk_epilogue_kernel, eg, dim3(256), 0, stream, a);
+      if (int rc = check_launch("splitk_epilogue")) return rc;
+    }
   }
-  return check_launch("gather_gemm");
+  return MOPOE_OK;
 }
 
 }  // namespace mopoe
 
 using namespace mopoe;
 
+extern "C" size_t mopoe_conv_workspace_bytes(void) { return WS_RECOMMENDED; }
+
 extern "C" int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const mopoe_conv_geom* g,
-                              const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats, void* stream) {
+                              const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_geom(g)) return rc;
   if (!x || !wp || !y) { set_error("conv_fwd: null pointer"); return MOPOE_ERR_ARG; }
+  const bool plain = (!bn_in || bn_in->mode == 0) && (!mask || mask->kind == 0);
+  // image-side edge layers: one channel on one side -> streaming kernels instead of a 98 %-padding GEMM tile
+  if (plain && !g->transposed && g->Cin == 1 && !bias && edge_supported(g, g->Cout, {wp, y}))
+    return edge_expand(x, wp, y, g, g->Cout, out_stats, (hipStream_t)stream);
+  if (plain && g->transposed && g->Cout == 1 && !out_stats && edge_supported(g, g->Cin, {x, wp}))
+    return edge_reduce(x, wp, bias, y, g, g->Cin, (hipStream_t)stream);
   // Conv: output on the small grid.  ConvTranspose: output on the big grid (phases).
   return launch_gather(x, wp, bias, y, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask, out_stats,
-                       nullptr, nullptr, nullptr, (hipStream_t)stream);
+                       nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
-                                const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* stream) {
+                                const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   if (int rc = validate_geom(g)) return rc;
   if (!dy || !wp || !dx) { set_error("conv_dgrad: null pointer"); return MOPOE_ERR_ARG; }
+  if (g->transposed && g->Cout == 1 && (!relu_bn || relu_bn->mode == 0) && edge_supported(g, g->Cin, {wp, dx}))
+    return edge_expand(dy, wp, dx, g, g->Cin, nullptr, (hipStream_t)stream);
   // input gradient of a Conv lives on the big grid (phases); of a ConvTranspose on the small grid.
   return launch_gather(dy, wp, nullptr, dx, g, g->transposed ? 1 : 0, g->Cout, g->Cin, /*w_nk=*/1, nullptr, nullptr,
-                       nullptr, relu_bn, xin, bwd_sums, (hipStream_t)stream);
+                       nullptr, relu_bn, xin, bwd_sums, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
@@ -563,6 +736,10 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   if (int rc = validate_geom(g)) return rc;
   if (!x || !dy || !dwp) { set_error("conv_wgrad: null pointer"); return MOPOE_ERR_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
+  if ((!bn_in || bn_in->mode == 0) && !g->transposed && g->Cin == 1 && edge_supported(g, g->Cout, {dy, dwp}))
+    return edge_wgrad(dy, x, dwp, g, g->Cout, stream);
+  if ((!bn_in || bn_in->mode == 0) && g->transposed && g->Cout == 1 && edge_supported(g, g->Cin, {x, dwp}))
+    return edge_wgrad(x, dy, dwp, g, g->Cin, stream);
   WgradArgs a;
   a.Xs = x; a.Dy = dy; a.dW = dwp;
   a.N = g->N; a.Hs = g->Hs; a.Ws = g->Ws; a.Hb = g->Hb; a.Wb = g->Wb; a.Cin = g->Cin; a.Cout = g->Cout;
@@ -595,7 +772,7 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
     if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
-  ProfScope prof(stream, flops);
+  ProfScope prof(stream, flops, big ? PROF_WGRAD128 : PROF_WGRAD64);
   dim3 grid(nI * nJ, taps, (unsigned)split);
   if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);

@@ -3,67 +3,9 @@
 // registers) and walks rows with a grid stride; loads/stores are 16 bytes per lane when C % 4 == 0.
 // Column reductions (BN statistics, BN-backward sums, bias gradients) are reduced per block through
 // LDS and leave the block as one atomic per column.
-#include "common.hpp"
+#include "ew_common.hpp"
 
 namespace mopoe {
-
-constexpr int EW_THREADS = 256;
-constexpr int EW_MAX_BLOCKS = 2048;
-
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<4> {
-  float v[4];
-  __device__ static Vec ld(const float* p) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    Vec r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
-  }
-  __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <>
-struct Vec<1> {
-  float v[1];
-  __device__ static Vec ld(const float* p) { Vec r; r.v[0] = *p; return r; }
-  __device__ void st(float* p) const { *p = v[0]; }
-};
-
-// column layout of a block: `cols` vector-columns per pass, `rpp` rows per pass
-struct ColLayout {
-  int Cv, cols, rpp, tc, tr;
-  __device__ ColLayout(int C, int VEC) {
-    Cv = (C + VEC - 1) / VEC;
-    cols = Cv < EW_THREADS ? Cv : EW_THREADS;
-    rpp = EW_THREADS / cols;
-    tc = threadIdx.x % cols;
-    tr = threadIdx.x / cols;
-  }
-};
-
-// reduce NACC per-thread partials (per channel of the thread's vector) over the block's row dimension
-// and add them to out[k][channel] (double, atomics) or outf (float, atomics)
-template <int VEC, int NACC>
-__device__ void block_col_reduce(const ColLayout& L, bool active, int cbase, int C, float (&part)[NACC][VEC],
-                                 double* const (&outd)[NACC], float* const (&outf)[NACC]) {
-  __shared__ float red[EW_THREADS * NACC * VEC];
-  __syncthreads();
-  for (int k = 0; k < NACC; ++k)
-    for (int e = 0; e < VEC; ++e) red[(threadIdx.x * NACC + k) * VEC + e] = active ? part[k][e] : 0.f;
-  __syncthreads();
-  if (L.tr == 0 && L.tc < L.cols) {
-    for (int k = 0; k < NACC; ++k) {
-      if (!outd[k] && !outf[k]) continue;
-      for (int e = 0; e < VEC; ++e) {
-        const int c = (cbase + L.tc) * VEC + e;
-        if (c >= C) continue;
-        float s = 0.f;
-        for (int r = 0; r < L.rpp; ++r) s += red[((r * L.cols + L.tc) * NACC + k) * VEC + e];
-        if (outd[k]) atomic_add_f64(outd[k] + c, (double)s);
-        if (outf[k]) unsafeAtomicAdd(outf[k] + c, s);
-      }
-    }
-  }
-}
 
 // ---- out = a*bn(s) + b*m  (+ stats of out) -----------------------------------------------------------
 template <int VEC>
@@ -159,9 +101,11 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* 
         const long off = r * C + (long)cv * VEC;
         const Vec<VEC> vg = Vec<VEC>::ld(g + off), vs = Vec<VEC>::ld(s + off);
         Vec<VEC> om, os;
+        const float* mrow = nullptr;
+        if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
+        else if (mask.kind == 2) mrow = mask.mask + r * C;
         for (int e = 0; e < VEC; ++e) {
-          float mk = 1.f;
-          if (mask.kind != 0) mk = mask_at(mask, r, cv * VEC + e, C);
+          const float mk = mrow ? mrow[cv * VEC + e] : 1.f;
           om.v[e] = b * vg.v[e] * mk;
           const float shat = (vs.v[e] - mean[e]) * rstd[e];
           os.v[e] = gr[e] * (vg.v[e] - k1[e] - shat * k2[e]);
@@ -210,10 +154,13 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
         const Vec<VEC> vd = Vec<VEC>::ld(dy + off), vx = Vec<VEC>::ld(x + off);
         Vec<VEC> va, o;
         if (add) va = Vec<VEC>::ld(add + off);
+        const float* mrow = nullptr;
+        if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
+        else if (mask.kind == 2) mrow = mask.mask + r * C;
         for (int e = 0; e < VEC; ++e) {
           const float xhat = (vx.v[e] - mean[e]) * rstd[e];
           float v = gr[e] * (vd.v[e] - k1[e] - xhat * k2[e]);
-          if (mask.kind != 0) v *= mask_at(mask, r, cv * VEC + e, C);
+          if (mrow) v *= mrow[cv * VEC + e];
           if (add) v += va.v[e];
           o.v[e] = v;
           part[0][e] += v;
@@ -262,25 +209,6 @@ __global__ void bn_running_kernel(const mopoe_bn_running_desc* desc, float momen
     d.rmean[c] = (1.f - momentum) * d.rmean[c] + momentum * (float)m;
     d.rvar[c] = (1.f - momentum) * d.rvar[c] + momentum * (float)(v * unb);
   }
-}
-
-static int ew_grid(long rows, int C, int VEC) {
-  const int Cv = (C + VEC - 1) / VEC;
-  const int cols = Cv < EW_THREADS ? Cv : EW_THREADS;
-  const int rpp = EW_THREADS / cols;
-  long blocks = (rows + rpp - 1) / rpp;
-  // keep several rows per thread so the per-block reduction / atomics amortise
-  blocks = (blocks + 3) / 4;
-  if (blocks < 1) blocks = 1;
-  if (blocks > EW_MAX_BLOCKS) blocks = EW_MAX_BLOCKS;
-  return (int)blocks;
-}
-
-static bool vec_ok(int C, std::initializer_list<const void*> ptrs) {
-  if (C % 4 != 0) return false;
-  for (const void* p : ptrs)
-    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
-  return true;
 }
 
 }  // namespace mopoe

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -173,6 +173,19 @@ def _mask(m: Optional[Mask]):
     return C.byref(m.c()) if m is not None else C.byref(_NO_MASK)
 
 
+_conv_ws = {}
+
+
+def _workspace(device):
+    """Per-device scratch for the split reductions of small-grid conv layers (C ABI: caller-owned)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _conv_ws:
+        lib().mopoe_conv_workspace_bytes.restype = C.c_size_t
+        nbytes = int(lib().mopoe_conv_workspace_bytes())
+        _conv_ws[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes)
+    return _conv_ws[key]
+
+
 def new_stats(n_channels: int, device) -> torch.Tensor:
     return torch.zeros(2, n_channels, dtype=torch.float64, device=device)
 
@@ -186,8 +199,9 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
     assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
     y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
     gc = g.c()
+    ws, nbytes = _workspace(x.device)
     _check(lib().mopoe_conv_fwd(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), _bn(bn_in), _mask(mask),
-                                _p(out_stats), _stream()))
+                                _p(out_stats), _p(ws), C.c_size_t(nbytes), _stream()))
     return y
 
 
@@ -196,8 +210,9 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
     assert tuple(dy.shape) == g.out_shape
     dx = torch.empty(g.in_shape, dtype=torch.float32, device=dy.device)
     gc = g.c()
+    ws, nbytes = _workspace(dy.device)
     _check(lib().mopoe_conv_dgrad(_p(dy), _p(wp), _p(dx), C.byref(gc), _bn(relu_bn), _p(xin), _p(bwd_sums),
-                                  _stream()))
+                                  _p(ws), C.c_size_t(nbytes), _stream()))
     return dx
 
 
@@ -225,21 +240,25 @@ def block_out_fwd(s, m, bn_s: Bn, a=RES_A, b=RES_B, out_stats=None):
     return out
 
 
-def bn_bwd_reduce(g, s, bn_s: Bn):
-    _dev(g, s)
-    sums = new_stats(s.shape[-1], s.device)
+def bn_bwd_reduce(g, s, bn_s: Bn, sums=None):
+    """sums: optional pre-zeroed double [2, C] (callers batch these allocations)."""
+    _dev(g, s, sums)
+    if sums is None:
+        sums = new_stats(s.shape[-1], s.device)
     _check(lib().mopoe_bn_bwd_reduce(_p(g), _p(s), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s), _p(sums),
                                      _stream()))
     return sums
 
 
 def block_out_bwd(g, s, bn_s: Bn, sums, mask: Optional[Mask], a=RES_A, b=RES_B, want_colsum_dm=False,
-                  want_colsum_ds=True):
-    """-> dm, ds, dgamma_s, dbeta_s, colsum_dm (or None), colsum_ds (or None)"""
+                  want_colsum_ds=True, small=None):
+    """-> dm, ds, dgamma_s, dbeta_s, colsum_dm (or None), colsum_ds (or None)
+    small: optional pre-zeroed float [4, C] that receives dgamma, dbeta and the two column sums."""
     _dev(g, s, sums)
     c = s.shape[-1]
     dm, ds = torch.empty_like(g), torch.empty_like(g)
-    small = torch.zeros(4, c, dtype=torch.float32, device=g.device)
+    if small is None:
+        small = torch.zeros(4, c, dtype=torch.float32, device=g.device)
     cdm = small[2] if want_colsum_dm else None
     cds = small[3] if want_colsum_ds else None
     _check(lib().mopoe_block_out_bwd(_p(g), _p(s), _p(dm), _p(ds), C.c_int64(_rows(s)), c, _bn(bn_s),
@@ -248,12 +267,13 @@ def block_out_bwd(g, s, bn_s: Bn, sums, mask: Optional[Mask], a=RES_A, b=RES_B, 
     return dm, ds, small[0], small[1], cdm, cds
 
 
-def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, want_colsum=False):
-    """-> dx, dgamma, dbeta, colsum_dx (or None)"""
+def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, want_colsum=False, small=None):
+    """-> dx, dgamma, dbeta, colsum_dx (or None); small: optional pre-zeroed float [3, C]."""
     _dev(dy, x, sums, add)
     c = x.shape[-1]
     dx = torch.empty_like(x)
-    small = torch.zeros(3, c, dtype=torch.float32, device=x.device)
+    if small is None:
+        small = torch.zeros(3, c, dtype=torch.float32, device=x.device)
     cs = small[2] if want_colsum else None
     _check(lib().mopoe_bn_bwd_apply(_p(dy), _p(x), _p(add), _p(dx), C.c_int64(_rows(x)), c, _bn(bn), _p(sums),
                                     _mask(mask), _p(small[0]), _p(small[1]), _p(cs), _stream()))
@@ -296,7 +316,7 @@ _kl_ws = {}
 
 
 def _ws(device, n=8):
-    key = (device.type, device.index, n)
+    key = (device.type, device.index, n, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     if key not in _kl_ws:
         _kl_ws[key] = torch.zeros(n, dtype=torch.float64, device=device)
     return _kl_ws[key]
@@ -411,7 +431,13 @@ def prof_enable(on: bool):
     _check(lib().mopoe_prof_enable(int(on)))
 
 
+PROF_KINDS = ("gather_gemm_kernel<128,128,2,2>", "gather_gemm_kernel<64,64,2,2>", "wgrad_gemm_kernel<128,128>",
+              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,1>")
+
+
 def prof_collect():
-    n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-    _check(lib().mopoe_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)))
-    return n.value, ms.value, fl.value
+    """-> {kernel kind: (launches, total ms, total algorithmic flops)} since the last collect"""
+    k = len(PROF_KINDS)
+    n, ms, fl = (C.c_int64 * k)(), (C.c_double * k)(), (C.c_double * k)()
+    _check(lib().mopoe_prof_collect(n, ms, fl))
+    return {name: (n[i], ms[i], fl[i]) for i, name in enumerate(PROF_KINDS)}

@@ -38,7 +38,23 @@ class MaskSource:
     def __init__(self, replay: Optional[Dict[str, torch.Tensor]] = None, prefix: str = ""):
         self.replay, self.prefix = replay, prefix
 
+    def begin(self, sizes, device):
+        """Draw every mask of one network forward with a single Bernoulli launch (p = 0.5, multiplier 2);
+        get() then hands out consecutive slices.  No-op when masks are replayed."""
+        self._pool, self._off = None, 0
+        if self.replay is None and sizes:
+            self._pool = torch.empty(sum(sizes), dtype=torch.float32, device=device).bernoulli_(0.5).mul_(2.0)
+
+    def _take(self, count):
+        v = self._pool[self._off:self._off + count]
+        self._off += count
+        return v
+
     def get(self, name: str, n: int, rows_per_sample: int, c: int, twod: bool, device) -> Mask:
+        if self.replay is None and getattr(self, "_pool", None) is not None:
+            if twod:
+                return Mask(self._take(n * c).view(n, c), 1, rows_per_sample)
+            return Mask(self._take(n * rows_per_sample * c).view(n, rows_per_sample, c), 2, rows_per_sample)
         if self.replay is not None:
             m = self.replay[self.prefix + name].to(device=device, dtype=torch.float32)
             if twod:
@@ -86,6 +102,13 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
     Returns (out, saved) where saved is the per-block state the backward needs."""
     saved = []
     running = []
+    if dropout:
+        sizes = []
+        for spec in blocks:
+            rin = spec.g1.Hs * spec.g1.Ws
+            rout = spec.g2.Hb * spec.g2.Wb if spec.g2.transposed else spec.g2.Hs * spec.g2.Ws
+            sizes += [batch * spec.g1.Cout * (1 if spec.twod else rin), batch * spec.g2.Cout * (1 if spec.twod else rout)]
+        masks.begin(sizes, x.device)
     for spec in blocks:
         p, g1, g2 = spec.params, spec.g1.with_batch(batch), spec.g2.with_batch(batch)
         rows_in = x.numel() // x.shape[-1]
@@ -122,16 +145,34 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
 def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor]):
     """g: gradient w.r.t. the trunk output.  Fills ``grads`` (keyed by parameter name relative to the
     network) and returns the gradient w.r.t. the trunk input."""
+    # one zero-filled arena for every small reduction buffer of this backward (instead of ~8 fills per block)
+    nd = sum(2 * b.g2.Cout + 4 * b.g1.Cin for b in blocks)
+    nf = sum(4 * b.g2.Cout + 6 * b.g1.Cin for b in blocks)
+    dbuf = torch.zeros(nd, dtype=torch.float64, device=g.device)
+    fbuf = torch.zeros(nf, dtype=torch.float32, device=g.device)
+    off = [0, 0]
+
+    def take_d(c):
+        v = dbuf[off[0]:off[0] + 2 * c].view(2, c)
+        off[0] += 2 * c
+        return v
+
+    def take_f(k, c):
+        v = fbuf[off[1]:off[1] + k * c].view(k, c)
+        off[1] += k * c
+        return v
+
     for spec, sv in zip(reversed(blocks), reversed(saved)):
         p, g1, g2 = spec.params, sv["g1"], sv["g2"]
         x, d1, s = sv["x"], sv["d1"], sv["s"]
         bn1, bn2, bns = sv["bn1"], sv["bn2"], sv["bns"]
         has_bias = p.conv1.bias is not None
         n = spec.name
-        sums_s = ops.bn_bwd_reduce(g, s, bns)
+        sums_s = ops.bn_bwd_reduce(g, s, bns, sums=take_d(g2.Cout))
         dm, ds, dgs, dbs, cdm, cds = ops.block_out_bwd(g, s, bns, sums_s, sv["mask2"],
-                                                       want_colsum_dm=has_bias, want_colsum_ds=True)
-        sums2 = ops.new_stats(g1.Cout, g.device)
+                                                       want_colsum_dm=has_bias, want_colsum_ds=True,
+                                                       small=take_f(4, g2.Cout))
+        sums2 = take_d(g1.Cout)
         dh2 = ops.conv_dgrad(dm, p.conv2.weight, g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
         grads[f"{n}.conv2.weight"] = ops.conv_wgrad(d1, dm, g2, bn_in=bn2)
         dxs = ops.conv_dgrad(ds, p.short[0].weight, g2)
@@ -139,15 +180,16 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         grads[f"{n}.{p.short_name}.0.bias"] = cds
         grads[f"{n}.{p.short_name}.1.weight"] = dgs
         grads[f"{n}.{p.short_name}.1.bias"] = dbs
-        dc1, dg2, db2, cdc1 = ops.bn_bwd_apply(dh2, d1, bn2, sums2, mask=sv["mask1"], want_colsum=has_bias)
+        dc1, dg2, db2, cdc1 = ops.bn_bwd_apply(dh2, d1, bn2, sums2, mask=sv["mask1"], want_colsum=has_bias,
+                                               small=take_f(3, g1.Cin))
         grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
-        sums1 = ops.new_stats(g1.Cin, g.device)
+        sums1 = take_d(g1.Cin)
         dh1 = ops.conv_dgrad(dc1, p.conv1.weight, g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
         grads[f"{n}.conv1.weight"] = ops.conv_wgrad(x, dc1, g1, bn_in=bn1)
         if has_bias:
             grads[f"{n}.conv2.bias"] = cdm
             grads[f"{n}.conv1.bias"] = cdc1
-        g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs)
+        g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin))
         grads[f"{n}.bn1.weight"], grads[f"{n}.bn1.bias"] = dg1, db1
     return g
 

@@ -136,7 +136,7 @@ def block_out_fwd(s, m, bn_s, a=RES_A, b=RES_B, out_stats=None):
     return out
 
 
-def bn_bwd_reduce(g, s, bn_s):
+def bn_bwd_reduce(g, s, bn_s, sums=None):
     mean, rstd, _, _ = bn_coef(bn_s)
     sums = torch.zeros(2, s.shape[-1], dtype=torch.float64, device=s.device)
     g2 = g.reshape(-1, g.shape[-1])
@@ -156,7 +156,7 @@ def _bn_bwd(dy, x, bn, sums):
     return bn.gamma * rstd * dy
 
 
-def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False, want_colsum_ds=True):
+def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False, want_colsum_ds=True, small=None):
     dm = b * g
     mm = _mask_mult(g, mask)
     if mm is not None:
@@ -170,7 +170,7 @@ def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False
     return dm.contiguous(), ds.contiguous(), dgamma, dbeta, cdm, cds
 
 
-def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False):
+def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=None):
     dx = _bn_bwd(dy, x, bn, sums)
     mm = _mask_mult(dx, mask)
     if mm is not None:
