@@ -1,0 +1,104 @@
+"""Data-parallel glue (mimic_amd.parallel + run_epochs.train_step) on CPU: world_size 2 over gloo.
+N ranks on N shards must equal one process that runs the N shards as micro-batches and averages the
+gradients (per-rank loss normalisation, per-rank BatchNorm statistics, mean of gradients).
+The HIP ops are replaced by their torch emulation (tests/torch_backend.py), as in test_host_logic_cpu."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+PATHS = [REPO, os.path.join(REPO, "mopoe-mimic_amd"), os.path.join(REPO, "oracle"), HERE]
+
+
+def _install_backend():
+    for p in PATHS:
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch_backend
+    from mimic_amd import ops
+    for name in torch_backend.OP_NAMES:
+        setattr(ops, name, getattr(torch_backend, name))
+
+
+def _make(cfg_seed=3):
+    import mopoe_ref as R
+    from model_util import build_exp
+    cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=3)
+    exp = build_exp(cfg, R.init_state(cfg, seed=cfg_seed), "cpu", "train_nodrop")
+    exp.set_optimizer()
+    return cfg, exp, R
+
+
+def _shard(R, cfg, rank):
+    batch, eps = R.synthetic_batch(cfg, 3, seed=50 + rank)
+    return batch, eps
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    _install_backend()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mimic_amd import run_epochs as RE
+    from mimic_amd.parallel import GradAllReducer
+    cfg, exp, R = _make(cfg_seed=3 + rank)          # different weights per rank: broadcast must fix that
+    reducer = GradAllReducer(exp.mm_vae, world, bucket_bytes=64 << 10)  # small buckets: several all-reduces
+    reducer.broadcast_parameters()
+    batch, eps = _shard(R, cfg, rank)
+    exp.mm_vae.eps_source = lambda b, d, dev: eps
+    pack = RE.ScalarPack(torch.device("cpu"))
+    routine = RE.basic_routine_epoch(exp, (batch, None))
+    exp.optimizer.zero_grad(set_to_none=True)
+    routine["total_loss"].backward()
+    reducer.all_reduce_grads()
+    pack.submit(routine, reducer)
+    scalars = pack.read()
+    grads = {n: p.grad.clone() for n, p in exp.mm_vae.named_parameters() if p.grad is not None}
+    torch.save({"grads": grads, "scalars": scalars, "loss": routine["total_loss"].item()},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_two_microbatches():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+    # both ranks hold identical averaged gradients
+    for n, g in res[0]["grads"].items():
+        torch.testing.assert_close(g, res[1]["grads"][n], rtol=0, atol=0)
+    # single-process reference: rank-0 weights, the two shards as micro-batches, mean of the gradients
+    _install_backend()
+    from mimic_amd import run_epochs as RE
+    cfg, exp, R = _make(cfg_seed=3)
+    acc, losses = {}, []
+    for r in range(world):
+        batch, eps = _shard(R, cfg, r)
+        exp.mm_vae.eps_source = lambda b, dd, dev, e=eps: e
+        out = RE.basic_routine_epoch(exp, (batch, None))
+        exp.mm_vae.zero_grad(set_to_none=True)
+        out["total_loss"].backward()
+        losses.append(out["total_loss"].item())
+        for n, p in exp.mm_vae.named_parameters():
+            if p.grad is not None:
+                acc[n] = acc.get(n, 0) + p.grad / world
+    assert set(acc) == set(res[0]["grads"])
+    # biases feeding a train-mode BatchNorm have analytically zero gradients (pure cancellation noise), so the
+    # absolute tolerance is tied to the largest gradient of the model, not to each tensor
+    gmax = max(g.abs().max().item() for g in acc.values())
+    for n, g in acc.items():
+        torch.testing.assert_close(res[0]["grads"][n], g, rtol=1e-4, atol=2e-6 * gmax, msg=n)
+    # the scalar pack is the mean over ranks (cross-GPU ELBO of the north-star)
+    assert abs(res[0]["scalars"]["total_loss"] - sum(losses) / world) <= 1e-5 * abs(sum(losses) / world)
+    assert abs(res[0]["loss"] - losses[0]) <= 1e-5 * abs(losses[0])  # per-rank loss stays per-rank
+    dead = [n for n, p in exp.mm_vae.named_parameters() if p.grad is None]
+    assert len(dead) == 24  # text resblock_7/8: skipped by the reducer instead of tripping DDP
