@@ -15,6 +15,7 @@
 // ([k][m], [k][n]) so that every MFMA operand read is a conflict-free ds_read_b32 of consecutive
 // lanes.  BatchNorm+ReLU of the operand, bias, dropout mask, BN statistics and the ReLU/BN backward
 // reductions are fused into the operand load / epilogue (see include/mopoe_hip.h).
+#include <stdlib.h>
 #include <algorithm>
 #include <initializer_list>
 
@@ -30,7 +31,10 @@ int edge_reduce(const float* x, const float* W, const float* bias, float* out, c
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x64 gather tile
+#ifndef GEMM_BK_BIG
+#define GEMM_BK_BIG 32           // K-chunk of the 128x128 / 256x64 gather tiles
+#endif
 constexpr int MAX_BN_C = 1024;
 constexpr int LDS_PAD = 4;
 
@@ -51,10 +55,20 @@ struct GemmArgs {
   mopoe_bn_ref relu_bn;
   const float* xin;
   double* bwd_sums;
+  unsigned x_bytes, w_bytes;   // sizes of X and W for the buffer descriptors (vector path)
   int nsplit;            // split-K factor (1 = none)
   float* partial;        // split-K: [nsplit][rows_total][Cn] raw partial sums (else nullptr)
   long rows_total;       // N*Hy*Wy
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;  // voffset past every buffer: the hardware range check returns zeros
+
+// 16-byte buffer load with hardware bounds check: no branch, no exec masking, zero for off >= bytes
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t srd, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
   // loads up to 4 consecutive floats starting at p; elements >= nvalid are zero
@@ -72,17 +86,22 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int GBK, bool VEC>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
   constexpr int TI = WM / 32, TJ = WN / 32;       // MFMA tiles per wave
   constexpr int A_LD = BM + LDS_PAD, B_LD = BN + LDS_PAD;
-  constexpr int A_PER_THR = BM / 64;              // float4 loads per thread for the A tile
-  constexpr int B_PER_THR = BN / 64;
+  constexpr int KQ = GBK / 4;                     // float4 per tile row along K
+  constexpr int RPP = 256 / KQ;                   // tile rows covered by one pass of the block
+  constexpr int A_PER_THR = BM / RPP;             // float4 loads per thread for the A tile
+  constexpr int B_PER_THR_NK = BN / RPP;          // weights with K contiguous (dgrad)
+  constexpr int N4 = BN / 4;                      // weights with N contiguous (forward): float4 per k-row
+  constexpr int B_PER_THR_KN = GBK / (256 / N4);
+  constexpr int B_PER_THR = B_PER_THR_NK > B_PER_THR_KN ? B_PER_THR_NK : B_PER_THR_KN;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BK][A_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][B_LD];
+  __shared__ __attribute__((aligned(16))) float As[2][GBK][A_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GBK][B_LD];
   __shared__ __attribute__((aligned(16))) float bnS[MAX_BN_C];
   __shared__ __attribute__((aligned(16))) float bnT[MAX_BN_C];
 
@@ -105,8 +124,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
     ky0 = ry; kx0 = rx; kstep_y = a.sh; kstep_x = a.sw; dsgn = -1;
     cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
   }
-  const int nkc = (a.Ck + BK - 1) / BK;
+  const int nkc = (a.Ck + GBK - 1) / GBK;
   const int total_all = nty * ntx * nkc;
+  // buffer descriptors (wave-uniform: kernel arguments only) for the branch-free vector path
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)a.w_bytes, 0x00020000);
   // split-K: this block reduces iterations [it_beg, it_end) of the flattened (tap, k-chunk) space
   const int per_split = (total_all + a.nsplit - 1) / a.nsplit;
   const int it_beg = split * per_split;
@@ -125,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
     __syncthreads();
   }
 
-  const int kq = tid & 3;
+  const int kq = tid % KQ;
+  const int trow = tid / KQ;
   const int l31 = lane & 31, lhi = lane >> 5;
   const bool do_relu_bn = a.relu_bn.mode != 0;
   const int hw = a.Hq * a.Wq;
@@ -147,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
     const long m0 = mt * BM;
 
     // ---- per-thread A rows -------------------------------------------------------------------------
-    int rn[A_PER_THR], ry0[A_PER_THR], rx0[A_PER_THR];
+    int rn[A_PER_THR], ry0[A_PER_THR], rx0[A_PER_THR], rbase[A_PER_THR];
     bool rvalid[A_PER_THR];
 #pragma unroll
     for (int i = 0; i < A_PER_THR; ++i) {
-      const long m = m0 + (tid >> 2) + i * 64;
+      const long m = m0 + trow + i * RPP;
       rvalid[i] = m < a.rows_per_phase;
       const unsigned mm = rvalid[i] ? (unsigned)m : 0u;   // rows_per_phase < 2^31 (checked on the host)
       const int n = (int)(mm / (unsigned)hw);
@@ -160,60 +183,74 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
       rn[i] = n;
       if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
       else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
+      rbase[i] = (n * a.Hx + ry0[i]) * a.Wx + rx0[i];   // source row of tap (0,0); < 2^31 (checked on the host)
     }
 
     float4 ra[A_PER_THR], rb[B_PER_THR];
+    // BN+ReLU of the operand is applied when the registers are written to LDS (store_tiles), i.e. AFTER the
+    // MFMA block that the global loads overlap with -- applying it at load time would put a vmcnt(0) wait
+    // right behind every load
+    float4 pend_sc = make_float4(0.f, 0.f, 0.f, 0.f), pend_sh = pend_sc;
+    bool pend_ok[A_PER_THR];
 
     auto load_tiles = [&](int it) {
       const int tap = it / nkc;
-      const int kc = (it - tap * nkc) * BK;
+      const int kc = (it - tap * nkc) * GBK;
       const int jy = tap / ntx, jx = tap - jy * ntx;
       const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
       const int ck = kc + kq * 4;
       const int nvk = a.Ck - ck;
-      float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
-      if (xform && nvk > 0) {
-        sc4 = *reinterpret_cast<const float4*>(&bnS[ck]);
-        sh4 = *reinterpret_cast<const float4*>(&bnT[ck]);
+      if (xform) {
+        const int cks = nvk > 0 ? ck : 0;
+        pend_sc = *reinterpret_cast<const float4*>(&bnS[cks]);
+        pend_sh = *reinterpret_cast<const float4*>(&bnT[cks]);
       }
+      const int tapoff = dsgn * (jy * a.Wx + jx);
 #pragma unroll
       for (int i = 0; i < A_PER_THR; ++i) {
         const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
         const bool ok = rvalid[i] && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && nvk > 0;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          const long row = ((long)rn[i] * a.Hx + iy) * a.Wx + ix;
-          v = ld4(a.X + row * a.Ck + ck, nvk, a.vecA);
-          if (xform) {
-            // table entries past Ck are zero, and so are the operand lanes past Ck (ld4): relu(0*0+0) = 0
-            v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
-            v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
-            v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
-          }
+        float4 v;
+        if constexpr (VEC) {
+          // Ck % 4 == 0 here, so a 4-channel group is either fully inside or fully outside
+          const unsigned off = ok ? ((unsigned)(rbase[i] + tapoff) * (unsigned)a.Ck + (unsigned)ck) * 4u : OOB;
+          v = bld4(srdX, off);
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) v = ld4(a.X + ((long)(rbase[i] + tapoff)) * a.Ck + ck, nvk, false);
         }
+        pend_ok[i] = ok;
         ra[i] = v;
       }
       if (a.w_nk == 0) {
-        constexpr int N4 = BN / 4;  // float4 per k-row
 #pragma unroll
-        for (int i = 0; i < B_PER_THR; ++i) {
+        for (int i = 0; i < B_PER_THR_KN; ++i) {
           const int k = tid / N4 + i * (256 / N4);
           const int n = n0 + (tid % N4) * 4;
           const int kk = kc + k;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kk < a.Ck && n < a.Cn)
-            v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, a.vecB);
-          rb[i] = v;
+          const bool ok = kk < a.Ck && n < a.Cn;
+          if constexpr (VEC) {
+            const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + kk) * (unsigned)a.Cout_w + n) * 4u : OOB;
+            rb[i] = bld4(srdW, off);
+          } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, false);
+            rb[i] = v;
+          }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < B_PER_THR; ++i) {
-          const int n = n0 + (tid >> 2) + i * 64;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (n < a.Cn && nvk > 0)
-            v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, a.vecB);
-          rb[i] = v;
+        for (int i = 0; i < B_PER_THR_NK; ++i) {
+          const int n = n0 + trow + i * RPP;
+          const bool ok = n < a.Cn && nvk > 0;
+          if constexpr (VEC) {
+            const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + n) * (unsigned)a.Cout_w + ck) * 4u : OOB;
+            rb[i] = bld4(srdW, off);
+          } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, false);
+            rb[i] = v;
+          }
         }
       }
     };
@@ -221,23 +258,31 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
       for (int i = 0; i < A_PER_THR; ++i) {
-        const int r = (tid >> 2) + i * 64;
+        const int r = trow + i * RPP;
+        if (xform) {
+          // table entries past Ck are zero, and so are the operand lanes past Ck: relu(0*0+0) = 0;
+          // spatial padding must stay zero AFTER the transform
+          const bool ok = pend_ok[i];
+          ra[i].x = ok ? fmaxf(fmaf(ra[i].x, pend_sc.x, pend_sh.x), 0.f) : 0.f;
+          ra[i].y = ok ? fmaxf(fmaf(ra[i].y, pend_sc.y, pend_sh.y), 0.f) : 0.f;
+          ra[i].z = ok ? fmaxf(fmaf(ra[i].z, pend_sc.z, pend_sh.z), 0.f) : 0.f;
+          ra[i].w = ok ? fmaxf(fmaf(ra[i].w, pend_sc.w, pend_sh.w), 0.f) : 0.f;
+        }
         As[buf][kq * 4 + 0][r] = ra[i].x;
         As[buf][kq * 4 + 1][r] = ra[i].y;
         As[buf][kq * 4 + 2][r] = ra[i].z;
         As[buf][kq * 4 + 3][r] = ra[i].w;
       }
       if (a.w_nk == 0) {
-        constexpr int N4 = BN / 4;
 #pragma unroll
-        for (int i = 0; i < B_PER_THR; ++i) {
+        for (int i = 0; i < B_PER_THR_KN; ++i) {
           const int k = tid / N4 + i * (256 / N4);
           *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < B_PER_THR; ++i) {
-          const int r = (tid >> 2) + i * 64;
+        for (int i = 0; i < B_PER_THR_NK; ++i) {
+          const int r = trow + i * RPP;
           Bs[buf][kq * 4 + 0][r] = rb[i].x;
           Bs[buf][kq * 4 + 1][r] = rb[i].y;
           Bs[buf][kq * 4 + 2][r] = rb[i].z;
@@ -264,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
       const int cur = it & 1;
       if (it + 1 < total) load_tiles(it_beg + it + 1);
 #pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
+      for (int kk = 0; kk < GBK / 2; ++kk) {
         const int k = kk * 2 + lhi;
         float av[TI], bv[TJ];
 #pragma unroll
@@ -390,10 +435,11 @@ struct WgradArgs {
   int nJ;            // number of J (Cout) tiles
   int atomic;        // 1: accumulate with atomics (split reduction)
   int vecI, vecJ;
+  unsigned x_bytes, dy_bytes;   // operand sizes for the buffer descriptors (vector path)
   mopoe_bn_ref bn_in;
 };
 
-template <int BI, int BJ>
+template <int BI, int BJ, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
   constexpr int WI = BI / 2, WJ = BJ / 2;
   constexpr int TI = WI / 32, TJ = WJ / 32;
@@ -403,8 +449,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
 
   __shared__ __attribute__((aligned(16))) float Is[2][BK][I_LD];
   __shared__ __attribute__((aligned(16))) float Js[2][BK][J_LD];
-  __shared__ float bnS[MAX_BN_C];
-  __shared__ float bnT[MAX_BN_C];
+  __shared__ __attribute__((aligned(16))) float bnS[MAX_BN_C];
+  __shared__ __attribute__((aligned(16))) float bnT[MAX_BN_C];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -419,8 +465,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
 
   const bool xform = a.bn_in.mode != 0;
   if (xform) {
-    for (int c = tid; c < a.Cin; c += 256) {
-      const BnC k = bn_coef(a.bn_in, c);
+    for (int c = tid; c < ((a.Cin + 3) & ~3); c += 256) {
+      BnC k = BnC{0.f, 0.f, 0.f, 0.f};
+      if (c < a.Cin) k = bn_coef(a.bn_in, c);
       bnS[c] = k.scale;
       bnT[c] = k.shift;
     }
@@ -428,17 +475,32 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
   }
 
   float4 ri[I_PER_THR], rj[J_PER_THR];
+  bool pend_ok[I_PER_THR];
   const int hw = a.Hs * a.Ws;
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xs, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdD = __builtin_amdgcn_make_buffer_rsrc((void*)a.Dy, 0, (int)a.dy_bytes, 0x00020000);
 
   // row index of pixel m in the small tensor (direct) and in the big tensor (gathered, -1 if padding)
-  auto rows_of = [&](long m, long& small_row, long& big_row) {
-    small_row = m;
-    const int n = (int)(m / hw);
-    const int rem = (int)(m - (long)n * hw);
+  auto rows_of = [&](unsigned m, int& small_row, int& big_row) {
+    small_row = (int)m;
+    const unsigned n = m / (unsigned)hw;
+    const unsigned rem = m - n * (unsigned)hw;
     const int qy = rem / a.Ws, qx = rem - qy * a.Ws;
     const int by = qy * a.sh - a.ph + ky, bx = qx * a.sw - a.pw + kx;
-    big_row = (by >= 0 && by < a.Hb && bx >= 0 && bx < a.Wb) ? ((long)n * a.Hb + by) * a.Wb + bx : -1;
+    big_row = (by >= 0 && by < a.Hb && bx >= 0 && bx < a.Wb) ? ((int)n * a.Hb + by) * a.Wb + bx : -1;
   };
+
+  // BN+ReLU of x is applied at LDS-store time (see gather_gemm_kernel): loads stay back-to-back
+  float4 sc4[I_PER_THR], sh4[I_PER_THR];
+  if (xform) {
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const int c = i0 + (tid % I4) * 4;
+      const int cs = c < a.Cin ? c : 0;
+      sc4[t] = *reinterpret_cast<const float4*>(&bnS[cs]);
+      sh4[t] = *reinterpret_cast<const float4*>(&bnT[cs]);
+    }
+  }
 
   auto load_tiles = [&](int it) {
     const long mb = mbeg + (long)it * BK;
@@ -447,37 +509,37 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
       const int p = tid / I4 + t * (256 / I4);
       const int c = i0 + (tid % I4) * 4;
       const long m = mb + p;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < mend && c < a.Cin) {
-        long srow, brow;
-        rows_of(m, srow, brow);
-        const long row = a.x_is_big ? brow : srow;
-        if (row >= 0) {
-          const int nv = a.Cin - c;
-          v = ld4(a.Xs + row * a.Cin + c, nv, a.vecI);
-          if (xform) {
-            v.x = fmaxf(fmaf(v.x, bnS[c], bnT[c]), 0.f);
-            if (nv > 1) v.y = fmaxf(fmaf(v.y, bnS[c + 1], bnT[c + 1]), 0.f);
-            if (nv > 2) v.z = fmaxf(fmaf(v.z, bnS[c + 2], bnT[c + 2]), 0.f);
-            if (nv > 3) v.w = fmaxf(fmaf(v.w, bnS[c + 3], bnT[c + 3]), 0.f);
-          }
-        }
+      int srow = 0, brow = -1;
+      const bool inm = m < mend && c < a.Cin;
+      rows_of(inm ? (unsigned)m : 0u, srow, brow);
+      const int row = a.x_is_big ? brow : srow;
+      const bool ok = inm && row >= 0;
+      pend_ok[t] = ok;
+      if constexpr (VEC) {
+        ri[t] = bld4(srdX, ok ? ((unsigned)row * (unsigned)a.Cin + (unsigned)c) * 4u : OOB);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = ld4(a.Xs + (long)row * a.Cin + c, a.Cin - c, false);
+        ri[t] = v;
       }
-      ri[t] = v;
     }
 #pragma unroll
     for (int t = 0; t < J_PER_THR; ++t) {
       const int p = tid / J4 + t * (256 / J4);
       const int c = j0 + (tid % J4) * 4;
       const long m = mb + p;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < mend && c < a.Cout) {
-        long srow, brow;
-        rows_of(m, srow, brow);
-        const long row = a.x_is_big ? srow : brow;
-        if (row >= 0) v = ld4(a.Dy + row * a.Cout + c, a.Cout - c, a.vecJ);
+      int srow = 0, brow = -1;
+      const bool inm = m < mend && c < a.Cout;
+      rows_of(inm ? (unsigned)m : 0u, srow, brow);
+      const int row = a.x_is_big ? srow : brow;
+      const bool ok = inm && row >= 0;
+      if constexpr (VEC) {
+        rj[t] = bld4(srdD, ok ? ((unsigned)row * (unsigned)a.Cout + (unsigned)c) * 4u : OOB);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = ld4(a.Dy + (long)row * a.Cout + c, a.Cout - c, false);
+        rj[t] = v;
       }
-      rj[t] = v;
     }
   };
 
@@ -485,6 +547,13 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < I_PER_THR; ++t) {
       const int p = tid / I4 + t * (256 / I4);
+      if (xform) {
+        const bool ok = pend_ok[t];
+        ri[t].x = ok ? fmaxf(fmaf(ri[t].x, sc4[t].x, sh4[t].x), 0.f) : 0.f;
+        ri[t].y = ok ? fmaxf(fmaf(ri[t].y, sc4[t].y, sh4[t].y), 0.f) : 0.f;
+        ri[t].z = ok ? fmaxf(fmaf(ri[t].z, sc4[t].z, sh4[t].z), 0.f) : 0.f;
+        ri[t].w = ok ? fmaxf(fmaf(ri[t].w, sc4[t].w, sh4[t].w), 0.f) : 0.f;
+      }
       *reinterpret_cast<float4*>(&Is[buf][p][(tid % I4) * 4]) = ri[t];
     }
 #pragma unroll
@@ -642,6 +711,12 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.rows_total = (long)g->N * a.Hy * a.Wy;
   a.vecA = (Ck % 4 == 0) && aligned16(X);
   a.vecB = (g->Cout % 4 == 0) && aligned16(W);
+  const size_t xb = (size_t)g->N * a.Hx * a.Wx * Ck * sizeof(float);
+  const size_t wb = (size_t)g->kh * g->kw * g->Cin * g->Cout * sizeof(float);
+  // branch-free buffer loads need 16-byte alignment, channel counts that are multiples of 4 and < 2 GiB operands
+  const bool vec = a.vecA && a.vecB && xb < (1ull << 31) && wb < (1ull << 31);
+  a.x_bytes = (unsigned)std::min<size_t>(xb, 0x7fffffffu);
+  a.w_bytes = (unsigned)std::min<size_t>(wb, 0x7fffffffu);
   mopoe_bn_ref none = {};
   mopoe_mask_ref nomask = {nullptr, 0, 1};
   a.bn_in = bn_in ? *bn_in : none;
@@ -650,11 +725,13 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
   a.nsplit = 1; a.partial = nullptr;
+  static const bool dbg_nostats = getenv("MOPOE_DEBUG_NOSTATS") != nullptr;  // timing experiments only
+  if (dbg_nostats) { a.out_stats = nullptr; a.bwd_sums = nullptr; }
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
   if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
   if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
   if (a.mask.kind == 1 && a.mask.rows_per_sample != a.Hy * a.Wy) { set_error("channel mask: rows_per_sample must be Hout*Wout"); return MOPOE_ERR_ARG; }
-  if (a.rows_total >= (1L << 31)) { set_error("conv: more than 2^31 output rows"); return MOPOE_ERR_ARG; }
+  if (a.rows_total >= (1L << 31) || (long)g->N * a.Hx * a.Wx >= (1L << 31)) { set_error("conv: more than 2^31 rows"); return MOPOE_ERR_ARG; }
 
   // ---- tile choice -------------------------------------------------------------------------------------------
   // 0: 128x128 (2x2 waves)   1: 256x64 (4x1 waves; narrow outputs, many rows)   2: 64x64 (2x2 waves)
@@ -667,11 +744,12 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
-  const int nkc = ceil_div(Ck, BK);
+  const int gbk = (cfg == 0) ? GEMM_BK_BIG : 16;
+  const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
-  if (ws && blocks < 160 && iters >= 16) {
-    long ns = std::min<long>((384 + blocks - 1) / blocks, iters / 8);
+  if (ws && blocks < 160 && iters * gbk >= 256) {
+    long ns = std::min<long>((384 + blocks - 1) / blocks, (long)iters * gbk / 128);
     const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
     if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
@@ -684,9 +762,15 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   {
     ProfScope prof(stream, flops, cfg == 0 ? PROF_GATHER128 : (cfg == 1 ? PROF_GATHER256x64 : PROF_GATHER64));
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
-    if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a);
-    else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, stream, a);
+    if (vec) {
+      if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, true>), grid, dim3(256), 0, stream, a);
+      else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, true>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, false>), grid, dim3(256), 0, stream, a);
+      else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, false>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, false>), grid, dim3(256), 0, stream, a);
+    }
     if (int rc = check_launch("gather_gemm")) return rc;
     if (a.partial) {
       dim3 eg(ceil_div(Cn, 64), ceil_div(a.rows_total, 4));
@@ -751,6 +835,13 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   if (a.bn_in.mode != 0 && (a.bn_in.C != g->Cin || g->Cin > MAX_BN_C)) { set_error("wgrad bn_in channel mismatch"); return MOPOE_ERR_ARG; }
   a.vecI = (g->Cin % 4 == 0) && aligned16(x);
   a.vecJ = (g->Cout % 4 == 0) && aligned16(dy);
+  const size_t rows_x = (size_t)g->N * (g->transposed ? g->Hs * g->Ws : g->Hb * g->Wb);
+  const size_t rows_dy = (size_t)g->N * (g->transposed ? g->Hb * g->Wb : g->Hs * g->Ws);
+  const size_t xb = rows_x * g->Cin * sizeof(float), db = rows_dy * g->Cout * sizeof(float);
+  const bool vec = a.vecI && a.vecJ && xb < (1ull << 31) && db < (1ull << 31);
+  a.x_bytes = (unsigned)std::min<size_t>(xb, 0x7fffffffu);
+  a.dy_bytes = (unsigned)std::min<size_t>(db, 0x7fffffffu);
+  if (rows_x >= (1ull << 31) || rows_dy >= (1ull << 31)) { set_error("wgrad: more than 2^31 rows"); return MOPOE_ERR_ARG; }
   const int taps = g->kh * g->kw;
   const bool big = g->Cin > 64 && g->Cout > 64;
   const int T = big ? 128 : 64;
@@ -774,7 +865,12 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   ProfScope prof(stream, flops, big ? PROF_WGRAD128 : PROF_WGRAD64);
   dim3 grid(nI * nJ, taps, (unsigned)split);
-  if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64>), grid, dim3(256), 0, stream, a);
+  if (vec) {
+    if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, true>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, false>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, false>), grid, dim3(256), 0, stream, a);
+  }
   return check_launch("wgrad_gemm");
 }
