@@ -32,8 +32,23 @@ int edge_reduce(const float* x, const float* W, const float* bias, float* out, c
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x64 gather tile
+#ifndef TILE_N64_REMAINDER
+#define TILE_N64_REMAINDER 8
+#endif
+#ifndef SPLIT_BLOCKS
+#define SPLIT_BLOCKS 256   // grids below this many blocks split the tap x channel reduction
+#endif
+#ifndef SPLIT_TARGET
+#define SPLIT_TARGET 512   // ... until about this many blocks are in flight
+#endif
+#ifndef PERSIST_BLOCKS
+#define PERSIST_BLOCKS 768   // upper bound on blocks of one launch (3 blocks per CU resident)
+#endif
+#ifndef GEMM_MIN_WAVES
+#define GEMM_MIN_WAVES 3
+#endif
 #ifndef GEMM_BK_BIG
-#define GEMM_BK_BIG 32           // K-chunk of the 128x128 / 256x64 gather tiles
+#define GEMM_BK_BIG 16           // K-chunk of the 128x128 / 256x64 gather tiles
 #endif
 constexpr int MAX_BN_C = 1024;
 constexpr int LDS_PAD = 4;
@@ -87,7 +102,7 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
 template <int BM, int BN, int WGM, int WGN, int GBK, bool VEC>
-__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const GemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
   constexpr int TI = WM / 32, TJ = WN / 32;       // MFMA tiles per wave
@@ -308,6 +323,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
     for (int it = 0; it < total; ++it) {
       const int cur = it & 1;
       if (it + 1 < total) load_tiles(it_beg + it + 1);
+#ifdef GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int kk = 0; kk < GBK / 2; ++kk) {
         const int k = kk * 2 + lhi;
@@ -322,6 +340,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GemmArgs a) {
           for (int j = 0; j < TJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
+#ifdef GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (it + 1 < total) store_tiles(cur ^ 1);
       __syncthreads();
     }
@@ -641,47 +662,53 @@ static int validate_geom(const mopoe_conv_geom* g) {
 }
 
 // ---- split-K epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums ------
-// block = 64 columns x 4 rows, ONE output element per thread; the nsplit partials are summed with 8
-// independent loads in flight per thread.
+// block = 64 columns x 4 row-lanes, grid-stride over rows (at most EPI_MAX_BLOCKS_Y blocks per column group so
+// that the column statistics leave as few same-address atomics as possible); the nsplit partials of one
+// element are independent loads.
+#ifndef EPI_MAX_BLOCKS_Y
+#define EPI_MAX_BLOCKS_Y 256
+#endif
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs a) {
   __shared__ float cs[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + tx;
-  const long row = (long)blockIdx.y * 4 + ty;
-  const bool ok = n < a.Cn && row < a.rows_total;
+  const bool nok = n < a.Cn;
   const bool do_relu_bn = a.relu_bn.mode != 0;
+  const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+  BnC rb = {0.f, 0.f, 0.f, 0.f};
+  if (nok && do_relu_bn) rb = bn_coef(a.relu_bn, n);
+  const long stride = a.rows_total * (long)a.Cn;
   float s1 = 0.f, s2 = 0.f;
-  if (ok) {
-    const long stride = a.rows_total * (long)a.Cn;
-    const float* p = a.partial + row * a.Cn + n;
-    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= a.nsplit; s += 8) {
+  if (nok) {
+    for (long row = (long)blockIdx.y * 4 + ty; row < a.rows_total; row += (long)gridDim.y * 4) {
+      const float* p = a.partial + row * a.Cn + n;
+      float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int s = 0;
+      for (; s + 8 <= a.nsplit; s += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc8[u] += p[(long)(s + u) * stride];
+        for (int u = 0; u < 8; ++u) acc8[u] += p[(long)(s + u) * stride];
+      }
+      for (; s < a.nsplit; ++s) acc8[s & 7] += p[(long)s * stride];
+      float x = bias + (((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7])));
+      if (a.mask.kind != 0) x *= mask_at(a.mask, row, n, a.Cn);
+      if (do_relu_bn) {
+        const float xi = a.xin[row * a.Cn + n];
+        x = (fmaf(xi, rb.scale, rb.shift) > 0.f) ? x : 0.f;
+        s1 += x;
+        s2 += x * ((xi - rb.mean) * rb.rstd);
+      } else {
+        s1 += x;
+        s2 += x * x;
+      }
+      a.Y[row * a.Cn + n] = x;
     }
-    for (; s < a.nsplit; ++s) acc8[0] += p[(long)s * stride];
-    float v = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-    if (a.bias) v += a.bias[n];
-    if (a.mask.kind != 0) v *= mask_at(a.mask, row, n, a.Cn);
-    if (do_relu_bn) {
-      const BnC rb = bn_coef(a.relu_bn, n);
-      const float xi = a.xin[row * a.Cn + n];
-      v = (fmaf(xi, rb.scale, rb.shift) > 0.f) ? v : 0.f;
-      s1 = v;
-      s2 = v * ((xi - rb.mean) * rb.rstd);
-    } else {
-      s1 = v;
-      s2 = v * v;
-    }
-    a.Y[row * a.Cn + n] = v;
   }
   double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
   if (sums) {
     cs[0][ty][tx] = s1;
     cs[1][ty][tx] = s2;
     __syncthreads();
-    if (ty == 0 && n < a.Cn) {
+    if (ty == 0 && nok) {
       atomic_add_f64(sums + n, (double)((cs[0][0][tx] + cs[0][1][tx]) + (cs[0][2][tx] + cs[0][3][tx])));
       atomic_add_f64(sums + a.Cn + n, (double)((cs[1][0][tx] + cs[1][1][tx]) + (cs[1][2][tx] + cs[1][3][tx])));
     }
@@ -740,6 +767,10 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   int cfg;
   if (Cn > 64) cfg = (a.rows_per_phase > 64 || Cn >= 256) ? 0 : 2;
   else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
+#ifdef TILE_N64_REMAINDER
+  // a 128-wide tile would be half empty for the last 64 columns (Cout = 192, 320): use 64-wide tiles instead
+  if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
+#endif
   const int bm = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64), bn = cfg == 0 ? 128 : 64;
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
@@ -748,14 +779,14 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
-  if (ws && blocks < 160 && iters * gbk >= 256) {
-    long ns = std::min<long>((384 + blocks - 1) / blocks, (long)iters * gbk / 128);
+  if (ws && blocks < SPLIT_BLOCKS && iters * gbk >= 256) {
+    long ns = std::min<long>((SPLIT_TARGET + blocks - 1) / blocks, (long)iters * gbk / 128);
     const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
     if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
-  long gx = std::min<long>(nMt, std::max<long>(1, 768 / ((long)nNt * nphase * a.nsplit)));
+  long gx = std::min<long>(nMt, std::max<long>(1, PERSIST_BLOCKS / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
@@ -773,7 +804,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     }
     if (int rc = check_launch("gather_gemm")) return rc;
     if (a.partial) {
-      dim3 eg(ceil_div(Cn, 64), ceil_div(a.rows_total, 4));
+      dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), EPI_MAX_BLOCKS_Y));
       hipLaunchKernelGGL(splitk_epilogue_kernel, eg, dim3(256), 0, stream, a);
       if (int rc = check_launch("splitk_epilogue")) return rc;
     }
