@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 2
+#define MOPOE_ABI_VERSION 3
 
 /* error codes */
 #define MOPOE_OK 0
@@ -103,9 +103,11 @@ int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_co
                      size_t workspace_bytes, void* stream);
 
 /* dwp[kh*kw][Cin][Cout] = d(conv)/d(weight); x is transformed by relu(bn(x)) when bn_in.mode != 0.
- * dwp is overwritten (the library zero-fills it first when it splits the pixel reduction). */
+ * dwp is overwritten; when the pixel reduction is split across blocks the partial products are accumulated
+ * with atomics into a zero-filled dwp: the library zero-fills it unless the caller states dwp_is_zero != 0
+ * (callers that carve all weight gradients of a network out of one zeroed arena save ~100 memsets a step). */
 int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
-                     const mopoe_bn_ref* bn_in, void* stream);
+                     const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, void* stream);
 
 /* ---- residual-block glue (HBM-bound elementwise + column reductions) -----------------------------
  * out = a * bn_s(s) + b * m           (ResidualBlocks.py:31-32,63-64,95-96,129-130 with the

@@ -847,7 +847,7 @@ extern "C" int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, con
 }
 
 extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
-                                const mopoe_bn_ref* bn_in, void* stream_) {
+                                const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, void* stream_) {
   if (int rc = validate_geom(g)) return rc;
   if (!x || !dy || !dwp) { set_error("conv_wgrad: null pointer"); return MOPOE_ERR_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
@@ -890,7 +890,7 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   a.chunk = chunk;
   a.atomic = split > 1;
   const size_t bytes = (size_t)taps * g->Cin * g->Cout * sizeof(float);
-  if (a.atomic) {
+  if (a.atomic && !dwp_is_zero) {
     if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;

@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -216,12 +216,15 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
     return dx
 
 
-def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None):
-    _dev(x, dy)
+def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
+    """out: optional ZERO-FILLED [taps, Cin, Cout] destination (e.g. a slice of a per-network gradient arena)."""
+    _dev(x, dy, out)
     assert tuple(x.shape) == g.in_shape and tuple(dy.shape) == g.out_shape
-    dwp = torch.empty((g.taps, g.Cin, g.Cout), dtype=torch.float32, device=x.device)
+    dwp = out if out is not None else torch.empty((g.taps, g.Cin, g.Cout), dtype=torch.float32, device=x.device)
+    assert tuple(dwp.shape) == (g.taps, g.Cin, g.Cout)
     gc = g.c()
-    _check(lib().mopoe_conv_wgrad(_p(x), _p(dy), _p(dwp), C.byref(gc), _bn(bn_in), _stream()))
+    _check(lib().mopoe_conv_wgrad(_p(x), _p(dy), _p(dwp), C.byref(gc), _bn(bn_in), C.c_int32(int(out is not None)),
+                                  _stream()))
     return dwp
 
 
@@ -280,19 +283,31 @@ def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, wan
     return dx, small[0], small[1], cs
 
 
+_run_desc_cache = {}
+
+
 def bn_running_update(entries: Sequence, momentum=0.1):
-    """entries: iterable of (sums double[2,C], running_mean, running_var, count)."""
+    """entries: iterable of (sums double[2,C], running_mean, running_var, count).
+    The device-side descriptor table is cached by the pointers it holds: in steady state the caching
+    allocator hands the statistics arena the same address every step, so no host->device copy (which
+    would be a stream-synchronising pageable copy) happens inside the step."""
     entries = list(entries)
     if not entries:
-        return
-    arr = (_RunDesc * len(entries))()
-    for i, (sums, rm, rv, count) in enumerate(entries):
-        _dev(sums, rm, rv)
-        arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
-    raw = bytes(arr)
-    desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(entries[0][1].device, non_blocking=False)
+        return None
+    key = tuple((s.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), c) for s, rm, rv, c in entries)
+    desc = _run_desc_cache.get(key)
+    if desc is None:
+        arr = (_RunDesc * len(entries))()
+        for i, (sums, rm, rv, count) in enumerate(entries):
+            _dev(sums, rm, rv)
+            arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        desc = host.to(entries[0][1].device)
+        if len(_run_desc_cache) > 256:
+            _run_desc_cache.clear()
+        _run_desc_cache[key] = desc
     _check(lib().mopoe_bn_running_update(_p(desc), len(entries), C.c_float(momentum), _stream()))
-    return desc  # keep alive until the stream has consumed it
+    return desc
 
 
 def colsum(x):

@@ -148,9 +148,18 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
     # one zero-filled arena for every small reduction buffer of this backward (instead of ~8 fills per block)
     nd = sum(2 * b.g2.Cout + 4 * b.g1.Cin for b in blocks)
     nf = sum(4 * b.g2.Cout + 6 * b.g1.Cin for b in blocks)
+    # ... and one for the weight gradients of every conv in the trunk (their split reductions accumulate with
+    # atomics into zeroed memory: one fill instead of one memset per layer)
+    nw = sum(b.g1.taps * b.g1.Cin * b.g1.Cout + 2 * b.g2.taps * b.g2.Cin * b.g2.Cout for b in blocks)
     dbuf = torch.zeros(nd, dtype=torch.float64, device=g.device)
-    fbuf = torch.zeros(nf, dtype=torch.float32, device=g.device)
+    fbuf = torch.zeros(nf + nw, dtype=torch.float32, device=g.device)
     off = [0, 0]
+
+    def take_w(geom):
+        n = geom.taps * geom.Cin * geom.Cout
+        v = fbuf[off[1]:off[1] + n].view(geom.taps, geom.Cin, geom.Cout)
+        off[1] += n
+        return v
 
     def take_d(c):
         v = dbuf[off[0]:off[0] + 2 * c].view(2, c)
@@ -174,9 +183,9 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                        small=take_f(4, g2.Cout))
         sums2 = take_d(g1.Cout)
         dh2 = ops.conv_dgrad(dm, p.conv2.weight, g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
-        grads[f"{n}.conv2.weight"] = ops.conv_wgrad(d1, dm, g2, bn_in=bn2)
+        grads[f"{n}.conv2.weight"] = ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=take_w(g2))
         dxs = ops.conv_dgrad(ds, p.short[0].weight, g2)
-        grads[f"{n}.{p.short_name}.0.weight"] = ops.conv_wgrad(x, ds, g2)
+        grads[f"{n}.{p.short_name}.0.weight"] = ops.conv_wgrad(x, ds, g2, out=take_w(g2))
         grads[f"{n}.{p.short_name}.0.bias"] = cds
         grads[f"{n}.{p.short_name}.1.weight"] = dgs
         grads[f"{n}.{p.short_name}.1.bias"] = dbs
@@ -185,7 +194,7 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
         sums1 = take_d(g1.Cin)
         dh1 = ops.conv_dgrad(dc1, p.conv1.weight, g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
-        grads[f"{n}.conv1.weight"] = ops.conv_wgrad(x, dc1, g1, bn_in=bn1)
+        grads[f"{n}.conv1.weight"] = ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=take_w(g1))
         if has_bias:
             grads[f"{n}.conv2.bias"] = cdm
             grads[f"{n}.conv1.bias"] = cdc1

@@ -115,7 +115,7 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn=None, xin=None, bwd_sums=None):
     return dx
 
 
-def conv_wgrad(x, dy, g: Geom, bn_in=None):
+def conv_wgrad(x, dy, g: Geom, bn_in=None, out=None):
     h = _act(x, bn_in).permute(0, 3, 1, 2)
     w0 = _ref_weight(torch.zeros(g.taps, g.Cin, g.Cout, dtype=x.dtype, device=x.device), g).requires_grad_(True)
     with torch.enable_grad():
@@ -125,7 +125,11 @@ def conv_wgrad(x, dy, g: Geom, bn_in=None):
         dwp = dw.permute(2, 3, 0, 1)
     else:
         dwp = dw.permute(2, 3, 1, 0)
-    return dwp.reshape(g.taps, g.Cin, g.Cout).contiguous()
+    dwp = dwp.reshape(g.taps, g.Cin, g.Cout).contiguous()
+    if out is not None:
+        out.copy_(dwp)
+        return out
+    return dwp
 
 
 # ---- residual-block glue -----------------------------------------------------------------------
