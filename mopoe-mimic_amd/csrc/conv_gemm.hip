@@ -41,8 +41,11 @@ constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x6
 #ifndef SPLIT_TARGET
 #define SPLIT_TARGET 512   // ... until about this many blocks are in flight
 #endif
+#ifndef GEMM_8WAVES
+#define GEMM_8WAVES 1          // 512-thread blocks (8 waves, 64x32 per wave): 4 waves per SIMD hide the load/store phases
+#endif
 #ifndef PERSIST_BLOCKS
-#define PERSIST_BLOCKS 768   // upper bound on blocks of one launch (3 blocks per CU resident)
+#define PERSIST_BLOCKS 512   // upper bound on blocks of one launch (2 x 8-wave blocks per CU resident)
 #endif
 #ifndef GEMM_MIN_WAVES
 #define GEMM_MIN_WAVES 3
@@ -102,17 +105,19 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
 template <int BM, int BN, int WGM, int WGN, int GBK, bool VEC>
-__global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const GemmArgs a) {
-  static_assert(WGM * WGN == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 4)) void gather_gemm_kernel(const GemmArgs a) {
+  constexpr int NT = 64 * WGM * WGN;            // threads per block (4 or 8 waves)
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
   constexpr int TI = WM / 32, TJ = WN / 32;       // MFMA tiles per wave
   constexpr int A_LD = BM + LDS_PAD, B_LD = BN + LDS_PAD;
   constexpr int KQ = GBK / 4;                     // float4 per tile row along K
-  constexpr int RPP = 256 / KQ;                   // tile rows covered by one pass of the block
+  constexpr int RPP = NT / KQ;                    // tile rows covered by one pass of the block
   constexpr int A_PER_THR = BM / RPP;             // float4 loads per thread for the A tile
-  constexpr int B_PER_THR_NK = BN / RPP;          // weights with K contiguous (dgrad)
+  static_assert(BM % RPP == 0, "A tile rows must be a multiple of the rows covered per pass");
+  constexpr int B_PER_THR_NK = (BN + RPP - 1) / RPP;   // weights with K contiguous (dgrad)
   constexpr int N4 = BN / 4;                      // weights with N contiguous (forward): float4 per k-row
-  constexpr int B_PER_THR_KN = GBK / (256 / N4);
+  constexpr int B_PER_THR_KN = (GBK * N4 + NT - 1) / NT;
   constexpr int B_PER_THR = B_PER_THR_NK > B_PER_THR_KN ? B_PER_THR_NK : B_PER_THR_KN;
 
   __shared__ __attribute__((aligned(16))) float As[2][GBK][A_LD];
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
   // ---- BN(+ReLU) table for the operand transform -----------------------------------------------
   const bool xform = a.bn_in.mode != 0;
   if (xform) {
-    for (int c = tid; c < ((a.Ck + 3) & ~3); c += 256) {
+    for (int c = tid; c < ((a.Ck + 3) & ~3); c += NT) {
       BnC k = BnC{0.f, 0.f, 0.f, 0.f};
       if (c < a.Ck) k = bn_coef(a.bn_in, c);
       bnS[c] = k.scale;
@@ -240,10 +245,10 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
       if (a.w_nk == 0) {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_KN; ++i) {
-          const int k = tid / N4 + i * (256 / N4);
+          const int k = tid / N4 + i * (NT / N4);
           const int n = n0 + (tid % N4) * 4;
           const int kk = kc + k;
-          const bool ok = kk < a.Ck && n < a.Cn;
+          const bool ok = k < GBK && kk < a.Ck && n < a.Cn;
           if constexpr (VEC) {
             const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + kk) * (unsigned)a.Cout_w + n) * 4u : OOB;
             rb[i] = bld4(srdW, off);
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
 #pragma unroll
         for (int i = 0; i < B_PER_THR_NK; ++i) {
           const int n = n0 + trow + i * RPP;
-          const bool ok = n < a.Cn && nvk > 0;
+          const bool ok = trow + i * RPP < BN && n < a.Cn && nvk > 0;
           if constexpr (VEC) {
             const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + n) * (unsigned)a.Cout_w + ck) * 4u : OOB;
             rb[i] = bld4(srdW, off);
@@ -291,13 +296,14 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
       if (a.w_nk == 0) {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_KN; ++i) {
-          const int k = tid / N4 + i * (256 / N4);
-          *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
+          const int k = tid / N4 + i * (NT / N4);
+          if (k < GBK) *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
         }
       } else {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_NK; ++i) {
           const int r = trow + i * RPP;
+          if (r >= BN) continue;
           Bs[buf][kq * 4 + 0][r] = rb[i].x;
           Bs[buf][kq * 4 + 1][r] = rb[i].y;
           Bs[buf][kq * 4 + 2][r] = rb[i].z;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
   // ---- column statistics: one atomic per column per block ------------------------------------------------
   double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
   if (sums && !a.partial) {
-    __shared__ float cs[2][4][64];  // [stat][wave][column within the wave tile (<= 64)]
+    __shared__ float cs[2][WGM * WGN][64];  // [stat][wave][column within the wave tile (<= 64)]
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
       // lanes l and l+32 hold the same column
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gather_gemm_kernel(const 
     }
     __syncthreads();
     // waves with the same wn own the same columns: combine them, then one atomic per column
-    for (int c = tid; c < BN; c += 256) {
+    for (int c = tid; c < BN; c += NT) {
       const int wnc = c / WN, cc = c - wnc * WN;
       const int n = n0 + c;
       if (n < a.Cn) {
@@ -794,8 +800,13 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     ProfScope prof(stream, flops, cfg == 0 ? PROF_GATHER128 : (cfg == 1 ? PROF_GATHER256x64 : PROF_GATHER64));
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
     if (vec) {
+#if GEMM_8WAVES
+      if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 4, GEMM_BK_BIG, true>), grid, dim3(512), 0, stream, a);
+      else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 2, 16, true>), grid, dim3(512), 0, stream, a);
+#else
       if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, true>), grid, dim3(256), 0, stream, a);
       else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, true>), grid, dim3(256), 0, stream, a);
+#endif
       else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, true>), grid, dim3(256), 0, stream, a);
     } else {
       if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, false>), grid, dim3(256), 0, stream, a);

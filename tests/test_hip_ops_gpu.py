@@ -137,6 +137,18 @@ def test_conv_family(name, g: Geom):
     check(f"{name}/wgrad_bn", dw, dw_ref)
 
 
+@pytest.mark.parametrize("name,g", [
+    ("narrow_many_rows_C", Geom(16, 32, 32, 64, 64, 16, 8, 4, 4, 2, 2, 1, 1, False)),      # dgrad -> Cn=16: 256x64 tile, phases
+    ("narrow_many_rows_T", Geom(16, 32, 32, 64, 64, 12, 8, 4, 4, 2, 2, 1, 1, True)),       # fwd -> Cn=8: 256x64 tile, phases
+    ("narrow_1x1", Geom(5, 64, 64, 64, 64, 64, 64, 1, 1, 1, 1, 0, 0, False)),              # 20480 rows, 256x64 tile
+    ("wide_many_rows", Geom(6, 32, 32, 64, 64, 32, 192, 4, 4, 2, 2, 1, 1, False)),         # 128x128 + 64-wide remainder rule
+], ids=["narrow_C", "narrow_T", "narrow_1x1", "wide"])
+def test_conv_many_rows_tile_configs(name, g):
+    """Shapes with >= 16384 output rows: the persistent 256x64 / 128x128 8-wave tiles, in both weight
+    orientations and with every fused epilogue (the small-batch cases above only reach the 64x64 tile)."""
+    test_conv_family(name, g)
+
+
 def test_conv_large_rows_splitk_and_big_tiles():
     """shapes of the C2 config's heaviest layers at reduced batch: exercises the 128x128 tiles and the
     split pixel reduction of wgrad."""
