@@ -43,9 +43,14 @@ class _NetFn(torch.autograd.Function):
     def backward(ctx, *gouts):
         net = ctx.net
         gouts = [None if g is None else g.contiguous() for g in gouts]
-        gin, grads = net._run_backward(ctx.saved, ctx.in_needs_grad, *gouts)
+        gin, grads, arena = net._run_backward(ctx.saved, ctx.in_needs_grad, *gouts)
         ctx.saved = None
         plist = [grads.get(name) for name, _ in net._named_param_list()]
+        reducer = getattr(net, "_grad_reducer", None)
+        if reducer is not None:
+            # data parallelism: this network's gradients are complete -> start their all-reduce now, so it
+            # overlaps with the backward of the networks autograd has not reached yet
+            reducer.network_done(arena, [g for g in plist if g is not None])
         return (None, None, *gin, *plist)
 
 
@@ -172,13 +177,13 @@ class EncoderImg(_HipNet):
     def _run_backward(self, sv, in_needs_grad, gmu, glv):
         grads: Dict[str, torch.Tensor] = {}
         dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
-        g0 = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
         grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["x"], g0, sv["gs"])
         gx = None
         if in_needs_grad[0]:
             gx = ops.conv_dgrad(g0, self.feature_extractor.conv1.weight, sv["gs"])
             gx = gx.reshape(gx.shape[0], 1, gx.shape[1], gx.shape[2]) if gx.shape[3] == 1 else gx.permute(0, 3, 1, 2)
-        return [gx], grads
+        return [gx], grads, arena
 
 
 # =================================================================================================
@@ -267,11 +272,11 @@ class DecoderImg(_HipNet):
         grads[f"img_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], g4, sv["gh"])
         grads[f"img_generator.generator.{k}.bias"] = ops.colsum(g4)
         dht = ops.conv_dgrad(g4, self.head.weight, sv["gh"])
-        g0 = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)
         gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
-        return [gz], grads
+        return [gz], grads, arena
 
 
 # =================================================================================================
@@ -344,12 +349,12 @@ class EncoderText(_HipNet):
         grads: Dict[str, torch.Tensor] = {}
         fe = self.feature_extractor
         dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
-        g0 = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
         grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, sv["gs"])
         grads["feature_extractor.conv1.bias"] = ops.colsum(g0)
         demb = ops.conv_dgrad(g0, fe.conv1.weight, sv["gs"])
         grads["feature_extractor.embedding.weight"] = ops.embedding_bwd(sv["ids"], demb, fe.embedding.weight.shape[0], 0)
-        return [None], grads
+        return [None], grads, arena
 
 
 # =================================================================================================
@@ -427,8 +432,8 @@ class DecoderText(_HipNet):
         grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
         grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)
         dht = ops.conv_dgrad(glogits, self.head.weight, gh)
-        g0 = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)
         gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
-        return [gz], grads
+        return [gz], grads, arena

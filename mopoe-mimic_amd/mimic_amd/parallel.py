@@ -3,14 +3,20 @@
 Replaces DistributedDataParallel over gloo (reference: mimic/run_epochs.py:245-247,
 mimic/utils/utils.py:179-185).  Semantics kept: per-rank loss normalisation and
 per-rank BatchNorm statistics, gradients AVERAGED across ranks, parameters broadcast from rank 0 at
-start.  Differences by design: parameters that never receive a gradient (text resblock_7/8 at L=128)
-are simply skipped instead of tripping DDP's unused-parameter check; BatchNorm running statistics are
-not re-broadcast every forward (train-mode arithmetic never reads them) but on demand
-(``sync_buffers``) before evaluation / checkpointing; the per-step scalar pack is averaged across ranks
-in the same step (north-star: cross-GPU ELBO).
-
-xGMI is point-to-point (7 links per GPU), so gradients travel as a few large flat buckets: large
-messages let RCCL spread the reduce-scatter / all-gather halves over all links at once.
+start.  Differences by design:
+  * bucket = network.  Every residual-trunk gradient of a network is a view into ONE arena
+    (trunk.trunk_backward), so the arena is all-reduced in place -- no flatten / unflatten copies -- and the
+    collective is launched the moment that network's backward node finishes (nets._NetFn.backward), i.e. it
+    overlaps with the backward of the networks autograd has not reached yet (decoders first, encoders last).
+    Six large messages (20-70 MB) per step: xGMI is point-to-point (7 links per GPU), large messages let
+    RCCL spread its reduce-scatter / all-gather halves over all links.
+  * the few gradients outside the arenas (stems, heads, latent projections, embedding: ~3 % of the bytes)
+    travel in one flat staging bucket per network;
+  * parameters that never receive a gradient (text resblock_7/8 at L=128) are simply absent instead of
+    tripping DDP's unused-parameter check;
+  * BatchNorm running statistics are not re-broadcast every forward (train-mode arithmetic never reads
+    them) but on demand (``sync_buffers``) before evaluation / checkpointing;
+  * the per-step scalar pack is averaged across ranks in the same step (north-star: cross-GPU ELBO).
 """
 from __future__ import annotations
 
@@ -19,30 +25,27 @@ from typing import List
 import torch
 import torch.distributed as dist
 
-BUCKET_BYTES = 64 << 20  # 64 MiB of fp32 gradients per all-reduce
+NET_NAMES = ("encoder_pa", "encoder_lat", "encoder_text", "decoder_pa", "decoder_lat", "decoder_text")
 
 
 class GradAllReducer:
-    def __init__(self, module: torch.nn.Module, world_size: int, bucket_bytes: int = BUCKET_BYTES):
-        self.module, self.world_size, self.bucket_bytes = module, world_size, bucket_bytes
-        self._buckets: List[List[torch.nn.Parameter]] = []
-        self._flat: List[torch.Tensor] = []
+    def __init__(self, module: torch.nn.Module, world_size: int):
+        self.module, self.world_size = module, world_size
+        self._pending = []       # (work handle, arena)
+        self._avg = None
+        if world_size > 1:
+            backend = dist.get_backend()
+            self._avg = dist.ReduceOp.AVG if backend == "nccl" else None   # gloo has no AVG: SUM then scale
+            for name in NET_NAMES:
+                net = getattr(module, name, None)
+                if net is not None:
+                    net._grad_reducer = self
 
-    def _build(self):
-        params = [p for p in self.module.parameters() if p.grad is not None]
-        params.reverse()  # roughly the order backward produces them: decoders first
-        buckets, cur, size = [], [], 0
-        for p in params:
-            nbytes = p.numel() * p.element_size()
-            if cur and size + nbytes > self.bucket_bytes:
-                buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += nbytes
-        if cur:
-            buckets.append(cur)
-        self._buckets = buckets
-        self._flat = [torch.empty(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device) for b in buckets]
+    def detach(self):
+        for name in NET_NAMES:
+            net = getattr(self.module, name, None)
+            if net is not None and getattr(net, "_grad_reducer", None) is self:
+                net._grad_reducer = None
 
     def broadcast_parameters(self, src: int = 0):
         if self.world_size <= 1:
@@ -57,31 +60,46 @@ class GradAllReducer:
         for b in self.module.buffers():
             dist.broadcast(b, src)
 
-    def all_reduce_grads(self):
-        """Average .grad across ranks.  Buckets are reduced asynchronously, then copied back."""
+    def _launch(self, t: torch.Tensor):
+        op = self._avg if self._avg is not None else dist.ReduceOp.SUM
+        return dist.all_reduce(t, op=op, async_op=True)
+
+    def network_done(self, arena: torch.Tensor, grads: List[torch.Tensor]):
+        """Called from a network's backward node: ``arena`` holds (as views) the trunk gradients.  Autograd
+        adopts those views as ``param.grad`` (no copy) when the gradients were cleared with
+        ``zero_grad(set_to_none=True)``, so reducing the arena in place reduces ``param.grad``."""
         if self.world_size <= 1:
             return
-        live = [p for p in self.module.parameters() if p.grad is not None]
-        if not self._buckets or sum(len(b) for b in self._buckets) != len(live):
-            self._build()
-        works = []
-        for bucket, flat in zip(self._buckets, self._flat):
-            torch._foreach_copy_(_views(flat, bucket), [p.grad for p in bucket])
-            flat.div_(self.world_size)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for work, bucket, flat in zip(works, self._buckets, self._flat):
+        self._pending.append((self._launch(arena), arena))
+
+    def all_reduce_grads(self):
+        """Wait for the per-network collectives started during backward and finish averaging; then reduce, in
+        one flat staging bucket, every gradient that does not live in a reduced arena (stems, heads, latent
+        projections, embedding -- about 3 % of the bytes -- or everything, if autograd had to copy)."""
+        if self.world_size <= 1:
+            return
+        ranges = []
+        for work, t in self._pending:
             work.wait()
-            torch._foreach_copy_([p.grad for p in bucket], _views(flat, bucket))
+            if self._avg is None:
+                t.div_(self.world_size)
+            ranges.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+        self._pending.clear()
+        outside = [p.grad for p in self.module.parameters()
+                   if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]
+        if outside:
+            flat = torch.cat([g.reshape(-1) for g in outside])
+            self._launch(flat).wait()
+            if self._avg is None:
+                flat.div_(self.world_size)
+            off = 0
+            for g in outside:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
 
     def mean_scalars(self, packed: torch.Tensor) -> torch.Tensor:
-        packed = packed / self.world_size
+        if self._avg is not None:
+            dist.all_reduce(packed, op=self._avg)
+            return packed
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-        return packed
-
-
-def _views(flat: torch.Tensor, params):
-    out, off = [], 0
-    for p in params:
-        out.append(flat[off:off + p.numel()].view_as(p))
-        off += p.numel()
-    return out
+        return packed / self.world_size

@@ -6,8 +6,8 @@ run_epochs :231-272), re-designed around the device:
     subsets, no device->host sync inside the step: the reference has 21 `.item()`/`.cpu()` per step);
   * the 18 logged scalars (loss, 7 KL, 3 NLL, joint divergence, 3 x (mean mu, mean logvar)) are packed
     on the device and read back with ONE asynchronous copy per step;
-  * data parallelism = one process per GPU, gradients averaged with RCCL all-reduce on flat buckets
-    (mimic_amd.parallel), the scalar pack summed across ranks in the same step.
+  * data parallelism = one process per GPU; each network's gradient arena is all-reduced with RCCL the moment
+    its backward node finishes (mimic_amd.parallel), the scalar pack is averaged across ranks in the same step.
 """
 from __future__ import annotations
 

@@ -144,7 +144,9 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
 
 def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor]):
     """g: gradient w.r.t. the trunk output.  Fills ``grads`` (keyed by parameter name relative to the
-    network) and returns the gradient w.r.t. the trunk input."""
+    network) and returns (gradient w.r.t. the trunk input, gradient arena).  Every gradient of the trunk's
+    parameters is a view into the arena, so data parallelism can all-reduce a whole network with one
+    collective and no staging copies (mimic_amd.parallel)."""
     # one zero-filled arena for every small reduction buffer of this backward (instead of ~8 fills per block)
     nd = sum(2 * b.g2.Cout + 4 * b.g1.Cin for b in blocks)
     nf = sum(4 * b.g2.Cout + 6 * b.g1.Cin for b in blocks)
@@ -200,7 +202,7 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
             grads[f"{n}.conv1.bias"] = cdc1
         g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin))
         grads[f"{n}.bn1.weight"], grads[f"{n}.bn1.bias"] = dg1, db1
-    return g
+    return g, fbuf
 
 
 def apply_running_updates(running, momentum=0.1):
