@@ -213,11 +213,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
     float4 pend_sc = make_float4(0.f, 0.f, 0.f, 0.f), pend_sh = pend_sc;
     bool pend_ok[A_PER_THR];
 
-    auto load_tiles = [&](int it) {
-      const int tap = it / nkc;
-      const int kc = (it - tap * nkc) * GBK;
-      const int jy = tap / ntx, jx = tap - jy * ntx;
-      const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+    // (tap, k-chunk) position of the NEXT load: advanced incrementally; the per-tap part (source pixel of every
+    // row, bounds, weight slice) is recomputed only when the tap changes, the per-chunk part is one add
+    int ld_tap = it_beg / nkc;
+    int ld_kc = (it_beg - ld_tap * nkc) * GBK;
+    bool tap_dirty = true;
+    unsigned offA[A_PER_THR], offW = 0;
+    bool okA[A_PER_THR];
+
+    auto load_tiles = [&](int /*it*/) {
+      if (tap_dirty) {
+        const int jy = ld_tap / ntx, jx = ld_tap - jy * ntx;
+        const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+        const int tapoff = dsgn * (jy * a.Wx + jx);
+#pragma unroll
+        for (int i = 0; i < A_PER_THR; ++i) {
+          const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
+          okA[i] = rvalid[i] & ((unsigned)iy < (unsigned)a.Hx) & ((unsigned)ix < (unsigned)a.Wx);
+          offA[i] = (unsigned)(rbase[i] + tapoff) * (unsigned)a.Ck * 4u;
+        }
+        offW = (unsigned)wtap * (unsigned)a.Cin_w * (unsigned)a.Cout_w * 4u;
+        tap_dirty = false;
+      }
+      const int kc = ld_kc;
       const int ck = kc + kq * 4;
       const int nvk = a.Ck - ck;
       if (xform) {
@@ -225,19 +243,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
         pend_sc = *reinterpret_cast<const float4*>(&bnS[cks]);
         pend_sh = *reinterpret_cast<const float4*>(&bnT[cks]);
       }
-      const int tapoff = dsgn * (jy * a.Wx + jx);
 #pragma unroll
       for (int i = 0; i < A_PER_THR; ++i) {
-        const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
-        const bool ok = rvalid[i] && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && nvk > 0;
+        const bool ok = okA[i] & (nvk > 0);
         float4 v;
         if constexpr (VEC) {
           // Ck % 4 == 0 here, so a 4-channel group is either fully inside or fully outside
-          const unsigned off = ok ? ((unsigned)(rbase[i] + tapoff) * (unsigned)a.Ck + (unsigned)ck) * 4u : OOB;
-          v = bld4(srdX, off);
+          v = bld4(srdX, ok ? offA[i] + (unsigned)ck * 4u : OOB);
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) v = ld4(a.X + ((long)(rbase[i] + tapoff)) * a.Ck + ck, nvk, false);
+          if (ok) v = ld4(a.X + (long)(offA[i] >> 2) + ck, nvk, false);
         }
         pend_ok[i] = ok;
         ra[i] = v;
@@ -248,13 +263,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
           const int k = tid / N4 + i * (NT / N4);
           const int n = n0 + (tid % N4) * 4;
           const int kk = kc + k;
-          const bool ok = k < GBK && kk < a.Ck && n < a.Cn;
+          const bool ok = (k < GBK) & (kk < a.Ck) & (n < a.Cn);
           if constexpr (VEC) {
-            const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + kk) * (unsigned)a.Cout_w + n) * 4u : OOB;
-            rb[i] = bld4(srdW, off);
+            rb[i] = bld4(srdW, ok ? offW + ((unsigned)kk * (unsigned)a.Cout_w + (unsigned)n) * 4u : OOB);
           } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = ld4(a.W + ((long)wtap * a.Cin_w + kk) * a.Cout_w + n, a.Cn - n, false);
+            if (ok) v = ld4(a.W + (long)(offW >> 2) + (long)kk * a.Cout_w + n, a.Cn - n, false);
             rb[i] = v;
           }
         }
@@ -262,17 +276,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
 #pragma unroll
         for (int i = 0; i < B_PER_THR_NK; ++i) {
           const int n = n0 + trow + i * RPP;
-          const bool ok = trow + i * RPP < BN && n < a.Cn && nvk > 0;
+          const bool ok = (trow + i * RPP < BN) & (n < a.Cn) & (nvk > 0);
           if constexpr (VEC) {
-            const unsigned off = ok ? (((unsigned)wtap * a.Cin_w + n) * (unsigned)a.Cout_w + ck) * 4u : OOB;
-            rb[i] = bld4(srdW, off);
+            rb[i] = bld4(srdW, ok ? offW + ((unsigned)n * (unsigned)a.Cout_w + (unsigned)ck) * 4u : OOB);
           } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = ld4(a.W + ((long)wtap * a.Cin_w + n) * a.Cout_w + ck, nvk, false);
+            if (ok) v = ld4(a.W + (long)(offW >> 2) + (long)n * a.Cout_w + ck, nvk, false);
             rb[i] = v;
           }
         }
       }
+      // advance to the next chunk
+      ld_kc += GBK;
+      if (ld_kc >= nkc * GBK) { ld_kc = 0; ++ld_tap; tap_dirty = true; }
     };
 
     auto store_tiles = [&](int buf) {
