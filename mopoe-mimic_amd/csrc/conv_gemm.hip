@@ -523,65 +523,65 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
   const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xs, 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t srdD = __builtin_amdgcn_make_buffer_rsrc((void*)a.Dy, 0, (int)a.dy_bytes, 0x00020000);
 
-  // row index of pixel m in the small tensor (direct) and in the big tensor (gathered, -1 if padding)
-  auto rows_of = [&](unsigned m, int& small_row, int& big_row) {
-    small_row = (int)m;
+  static_assert(BI == BJ, "both operand tiles cover the same pixels per thread");
+  // Pixel coordinates of this thread's rows, advanced incrementally (16 pixels per K-step) instead of being
+  // re-derived with integer divisions every iteration.
+  constexpr int PPP = 256 / I4;                 // pixels covered per pass
+  int pn[I_PER_THR], pqy[I_PER_THR], pqx[I_PER_THR];
+  long pm[I_PER_THR];
+#pragma unroll
+  for (int t = 0; t < I_PER_THR; ++t) {
+    pm[t] = mbeg + tid / I4 + t * PPP;
+    const unsigned m = (unsigned)(pm[t] < a.Ms ? pm[t] : 0);
     const unsigned n = m / (unsigned)hw;
     const unsigned rem = m - n * (unsigned)hw;
-    const int qy = rem / a.Ws, qx = rem - qy * a.Ws;
-    const int by = qy * a.sh - a.ph + ky, bx = qx * a.sw - a.pw + kx;
-    big_row = (by >= 0 && by < a.Hb && bx >= 0 && bx < a.Wb) ? ((int)n * a.Hb + by) * a.Wb + bx : -1;
-  };
-
-  // BN+ReLU of x is applied at LDS-store time (see gather_gemm_kernel): loads stay back-to-back
-  float4 sc4[I_PER_THR], sh4[I_PER_THR];
-  if (xform) {
-#pragma unroll
-    for (int t = 0; t < I_PER_THR; ++t) {
-      const int c = i0 + (tid % I4) * 4;
-      const int cs = c < a.Cin ? c : 0;
-      sc4[t] = *reinterpret_cast<const float4*>(&bnS[cs]);
-      sh4[t] = *reinterpret_cast<const float4*>(&bnT[cs]);
-    }
+    pn[t] = (int)n; pqy[t] = rem / a.Ws; pqx[t] = rem - pqy[t] * a.Ws;
   }
 
-  auto load_tiles = [&](int it) {
-    const long mb = mbeg + (long)it * BK;
+  // BN+ReLU of x is applied at LDS-store time (see gather_gemm_kernel): loads stay back-to-back
+  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+  const int ci = i0 + (tid % I4) * 4, cj = j0 + (tid % J4) * 4;
+  if (xform) {
+    const int cs = ci < a.Cin ? ci : 0;
+    sc4 = *reinterpret_cast<const float4*>(&bnS[cs]);
+    sh4 = *reinterpret_cast<const float4*>(&bnT[cs]);
+  }
+
+  auto load_tiles = [&](int /*it*/) {
 #pragma unroll
     for (int t = 0; t < I_PER_THR; ++t) {
-      const int p = tid / I4 + t * (256 / I4);
-      const int c = i0 + (tid % I4) * 4;
-      const long m = mb + p;
-      int srow = 0, brow = -1;
-      const bool inm = m < mend && c < a.Cin;
-      rows_of(inm ? (unsigned)m : 0u, srow, brow);
-      const int row = a.x_is_big ? brow : srow;
-      const bool ok = inm && row >= 0;
-      pend_ok[t] = ok;
+      const bool inm = pm[t] < mend;
+      const int by = pqy[t] * a.sh - a.ph + ky, bx = pqx[t] * a.sw - a.pw + kx;
+      const bool inb = ((unsigned)by < (unsigned)a.Hb) & ((unsigned)bx < (unsigned)a.Wb);
+      const int srow = (int)pm[t];
+      const int brow = (pn[t] * a.Hb + by) * a.Wb + bx;
+      const int rowx = a.x_is_big ? brow : srow, rowd = a.x_is_big ? srow : brow;
+      const bool okx = inm & (ci < a.Cin) & (a.x_is_big ? inb : true);
+      const bool okd = inm & (cj < a.Cout) & (a.x_is_big ? true : inb);
+      pend_ok[t] = okx;
       if constexpr (VEC) {
-        ri[t] = bld4(srdX, ok ? ((unsigned)row * (unsigned)a.Cin + (unsigned)c) * 4u : OOB);
+        ri[t] = bld4(srdX, okx ? ((unsigned)rowx * (unsigned)a.Cin + (unsigned)ci) * 4u : OOB);
+        rj[t] = bld4(srdD, okd ? ((unsigned)rowd * (unsigned)a.Cout + (unsigned)cj) * 4u : OOB);
       } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = ld4(a.Xs + (long)row * a.Cin + c, a.Cin - c, false);
-        ri[t] = v;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+        if (okx) v = ld4(a.Xs + (long)rowx * a.Cin + ci, a.Cin - ci, false);
+        if (okd) w = ld4(a.Dy + (long)rowd * a.Cout + cj, a.Cout - cj, false);
+        ri[t] = v; rj[t] = w;
       }
-    }
-#pragma unroll
-    for (int t = 0; t < J_PER_THR; ++t) {
-      const int p = tid / J4 + t * (256 / J4);
-      const int c = j0 + (tid % J4) * 4;
-      const long m = mb + p;
-      int srow = 0, brow = -1;
-      const bool inm = m < mend && c < a.Cout;
-      rows_of(inm ? (unsigned)m : 0u, srow, brow);
-      const int row = a.x_is_big ? srow : brow;
-      const bool ok = inm && row >= 0;
-      if constexpr (VEC) {
-        rj[t] = bld4(srdD, ok ? ((unsigned)row * (unsigned)a.Cout + (unsigned)c) * 4u : OOB);
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = ld4(a.Dy + (long)row * a.Cout + c, a.Cout - c, false);
-        rj[t] = v;
+      // advance this row by BK pixels
+      pm[t] += BK;
+      pqx[t] += BK;
+      if (pqx[t] >= a.Ws) {
+        if (a.Ws >= BK) {
+          pqx[t] -= a.Ws; ++pqy[t];
+        } else {
+          const int carry = pqx[t] / a.Ws;
+          pqx[t] -= carry * a.Ws; pqy[t] += carry;
+        }
+        if (pqy[t] >= a.Hs) {
+          const int carry = pqy[t] / a.Hs;
+          pqy[t] -= carry * a.Hs; pn[t] += carry;
+        }
       }
     }
   };
@@ -592,10 +592,10 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
       const int p = tid / I4 + t * (256 / I4);
       if (xform) {
         const bool ok = pend_ok[t];
-        ri[t].x = ok ? fmaxf(fmaf(ri[t].x, sc4[t].x, sh4[t].x), 0.f) : 0.f;
-        ri[t].y = ok ? fmaxf(fmaf(ri[t].y, sc4[t].y, sh4[t].y), 0.f) : 0.f;
-        ri[t].z = ok ? fmaxf(fmaf(ri[t].z, sc4[t].z, sh4[t].z), 0.f) : 0.f;
-        ri[t].w = ok ? fmaxf(fmaf(ri[t].w, sc4[t].w, sh4[t].w), 0.f) : 0.f;
+        ri[t].x = ok ? fmaxf(fmaf(ri[t].x, sc4.x, sh4.x), 0.f) : 0.f;
+        ri[t].y = ok ? fmaxf(fmaf(ri[t].y, sc4.y, sh4.y), 0.f) : 0.f;
+        ri[t].z = ok ? fmaxf(fmaf(ri[t].z, sc4.z, sh4.z), 0.f) : 0.f;
+        ri[t].w = ok ? fmaxf(fmaf(ri[t].w, sc4.w, sh4.w), 0.f) : 0.f;
       }
       *reinterpret_cast<float4*>(&Is[buf][p][(tid % I4) * 4]) = ri[t];
     }
