@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x64 gather tile
 #ifndef TILE_N64_REMAINDER
-#define TILE_N64_REMAINDER 8
+#define TILE_N64_REMAINDER 64
 #endif
 #ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 256   // grids below this many blocks split the tap x channel reduction
