@@ -168,10 +168,20 @@ def main():
         name, (n, ms, fl) = max(prof.items(), key=lambda kv: kv[1][1])
         all_ms = sum(v[1] for v in prof.values())
         all_fl = sum(v[2] for v in prof.values())
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+            with open(os.path.join(REPO, "profiles", "latest_pmc_hbm.json")) as f:
+                pm = json.load(f)["kernels"]
+            key = name.split("<")[0]
+            cands = [v for k, v in pm.items() if k.startswith(key) and name.split("<")[1].split(",")[0] in k]
+            if cands:
+                traffic = max(cands, key=lambda v: v["launches"])["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         if n:
             achieved = fl / (ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                         "flops_per_launch": fl / n,
                         "all_gemm_kernels": {"ms_per_step": round(all_ms / nprof, 3),

@@ -446,8 +446,8 @@ def prof_enable(on: bool):
     _check(lib().mopoe_prof_enable(int(on)))
 
 
-PROF_KINDS = ("gather_gemm_kernel<128,128,2,2>", "gather_gemm_kernel<64,64,2,2>", "wgrad_gemm_kernel<128,128>",
-              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,1>")
+PROF_KINDS = ("gather_gemm_kernel<128,128,2,4,16>", "gather_gemm_kernel<64,64,2,2,16>", "wgrad_gemm_kernel<128,128>",
+              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,2,16>")
 
 
 def prof_collect():

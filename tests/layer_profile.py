@@ -62,3 +62,14 @@ def main():
               f"{'T' if g.transposed else 'C'} {g.Cin:4d}->{g.Cout:4d} k{g.kh}x{g.kw} s{g.sw} p{g.pw} small{g.Hs}x{g.Ws} big{g.Hb}x{g.Wb}")
 
 main()
+
+# aggregate: 1-D (text) vs 2-D / linear layers, by op
+def _summary():
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for name, g, e0, e1 in recs:
+        net = "text(1-D)" if (g.kh == 1 and g.kw == 4) or (g.Hs == 1 and g.Ws > 1) else "image+linear"
+        a = agg[(net, name.split("+")[0])]
+        a[0] += e0.elapsed_time(e1) / 3; a[1] += 1
+    for k, (t, c) in sorted(agg.items()):
+        print(f"{k}: {t:.3f} ms/step in {c/3:.0f} calls")
+_summary()
