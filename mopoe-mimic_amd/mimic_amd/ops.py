@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
+from functools import lru_cache
 from typing import Optional, Sequence
 
 import torch
@@ -82,12 +83,21 @@ class Geom:
         return self.kh * self.kw
 
     def with_batch(self, n):
-        return Geom(n, *[getattr(self, f) for f in
-                         ("Hs", "Ws", "Hb", "Wb", "Cin", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")])
+        return _with_batch(self, n)
 
     def c(self):
-        return _Geom(self.N, self.Hs, self.Ws, self.Hb, self.Wb, self.Cin, self.Cout, self.kh, self.kw,
-                     self.sh, self.sw, self.ph, self.pw, int(self.transposed))
+        return _geom_struct(self)
+
+
+@lru_cache(maxsize=None)
+def _with_batch(g: "Geom", n: int) -> "Geom":
+    return Geom(n, *[getattr(g, f) for f in
+                     ("Hs", "Ws", "Hb", "Wb", "Cin", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed")])
+
+
+@lru_cache(maxsize=None)
+def _geom_struct(g: "Geom") -> "_Geom":
+    return _Geom(g.N, g.Hs, g.Ws, g.Hb, g.Wb, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, int(g.transposed))
 
 
 @dataclass
@@ -152,8 +162,19 @@ def _check(rc: int):
         raise MopoeHipError(f"libmopoe_hip error {rc}: {lib().mopoe_last_error().decode()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_ptr(device=None) -> int:
+    """current HIP stream of the device as an integer (fast path: torch.cuda.current_stream() costs ~7 us)"""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_ptr())
 
 
 def _dev(*ts):
@@ -178,7 +199,7 @@ _conv_ws = {}
 
 def _workspace(device):
     """Per-device scratch for the split reductions of small-grid conv layers (C ABI: caller-owned)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_ptr(device))
     if key not in _conv_ws:
         lib().mopoe_conv_workspace_bytes.restype = C.c_size_t
         nbytes = int(lib().mopoe_conv_workspace_bytes())
@@ -331,7 +352,7 @@ _kl_ws = {}
 
 
 def _ws(device, n=8):
-    key = (device.type, device.index, n, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.index, n, _stream_ptr(device) if device.type == "cuda" else 0)
     if key not in _kl_ws:
         _kl_ws[key] = torch.zeros(n, dtype=torch.float64, device=device)
     return _kl_ws[key]

@@ -11,6 +11,7 @@ epilogue of the kernel that produces the tensor.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -67,6 +68,48 @@ class MaskSource:
         return Mask(m, 2, rows_per_sample)
 
 
+# Weight gradients are off the critical path of the backward chain (nothing downstream reads them before the
+# optimizer), so they are launched on a second HIP stream: on the deep / 1-D layers, whose grids cannot fill 256
+# CUs, the wgrad kernels then run concurrently with the dgrad / BatchNorm-backward chain instead of after it.
+WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device, which=0):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _WgradLane:
+    """Runs callables on a side stream after everything enqueued so far on the main stream.  Lane 0 carries the
+    weight gradients, lane 1 the projection-shortcut branch (its conv in the forward, its input gradient in the
+    backward), which is independent of the main conv1 -> conv2 chain until the residual mix."""
+
+    def __init__(self, device, which=0):
+        self.enabled = WGRAD_SIDE_STREAM and device.type == "cuda"
+        if self.enabled:
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_stream(device, which)
+        self.keep = []   # tensors the side stream reads: kept alive until join()
+
+    def run(self, fn, *inputs):
+        if not self.enabled:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.keep.extend(inputs)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            return fn()
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+        self.keep.clear()
+
+
 def _bn(p, training: bool, sums, count) -> Bn:
     if training:
         return Bn(p.weight, p.bias, 1, sums=sums, count=count)
@@ -102,6 +145,7 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
     Returns (out, saved) where saved is the per-block state the backward needs."""
     saved = []
     running = []
+    lane = _WgradLane(x.device, 1)
     if dropout:
         sizes = []
         for spec in blocks:
@@ -120,6 +164,9 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         if dropout:
             mask1 = masks.get(spec.name + ".dropout1", batch, rps_in, g1.Cout, spec.twod, x.device)
         st_d1 = arena.take(g1.Cout)
+        st_s = arena.take(g2.Cout)
+        sconv, sbn = p.short[0], p.short[1]
+        s = lane.run(lambda: ops.conv_fwd(x, sconv.weight, g2, bias=sconv.bias, out_stats=st_s), x)
         d1 = ops.conv_fwd(x, p.conv1.weight, g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
         bn2 = _bn(p.bn2, training, st_d1, rows_in)
         if training:
@@ -129,9 +176,7 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         if dropout:
             mask2 = masks.get(spec.name + ".dropout2", batch, rps_out, g2.Cout, spec.twod, x.device)
         m = ops.conv_fwd(d1, p.conv2.weight, g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
-        st_s = arena.take(g2.Cout)
-        sconv, sbn = p.short[0], p.short[1]
-        s = ops.conv_fwd(x, sconv.weight, g2, bias=sconv.bias, out_stats=st_s)
+        lane.join()
         bns = _bn(sbn, training, st_s, rows_out)
         if training:
             running.append((st_s, sbn, rows_out))
@@ -173,6 +218,8 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         off[1] += k * c
         return v
 
+    lane = _WgradLane(g.device, 0)
+    lane_s = _WgradLane(g.device, 1)
     for spec, sv in zip(reversed(blocks), reversed(saved)):
         p, g1, g2 = spec.params, sv["g1"], sv["g2"]
         x, d1, s = sv["x"], sv["d1"], sv["s"]
@@ -185,9 +232,10 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                        small=take_f(4, g2.Cout))
         sums2 = take_d(g1.Cout)
         dh2 = ops.conv_dgrad(dm, p.conv2.weight, g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
-        grads[f"{n}.conv2.weight"] = ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=take_w(g2))
-        dxs = ops.conv_dgrad(ds, p.short[0].weight, g2)
-        grads[f"{n}.{p.short_name}.0.weight"] = ops.conv_wgrad(x, ds, g2, out=take_w(g2))
+        w2, ws_ = take_w(g2), take_w(g2)
+        grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=w2), d1, dm)
+        grads[f"{n}.{p.short_name}.0.weight"] = lane.run(lambda: ops.conv_wgrad(x, ds, g2, out=ws_), x, ds)
+        dxs = lane_s.run(lambda: ops.conv_dgrad(ds, p.short[0].weight, g2), ds)
         grads[f"{n}.{p.short_name}.0.bias"] = cds
         grads[f"{n}.{p.short_name}.1.weight"] = dgs
         grads[f"{n}.{p.short_name}.1.bias"] = dbs
@@ -196,12 +244,15 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
         sums1 = take_d(g1.Cin)
         dh1 = ops.conv_dgrad(dc1, p.conv1.weight, g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
-        grads[f"{n}.conv1.weight"] = ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=take_w(g1))
+        w1 = take_w(g1)
+        grads[f"{n}.conv1.weight"] = lane.run(lambda: ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=w1), x, dc1)
         if has_bias:
             grads[f"{n}.conv2.bias"] = cdm
             grads[f"{n}.conv1.bias"] = cdc1
+        lane_s.join()
         g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin))
         grads[f"{n}.bn1.weight"], grads[f"{n}.bn1.bias"] = dg1, db1
+    lane.join()
     return g, fbuf
 
 
