@@ -131,10 +131,13 @@ def main():
     pack = RE.ScalarPack(device)
     torch.manual_seed(1234 + rank)
 
+    host_done = [0.0]
+
     def run(nsteps, start=0):
         for i in range(nsteps):
             b = batches[(start + i) % len(batches)]
             RE.train_step(exp, ({k: v for k, v in b[0].items()}, None), reducer, pack)
+        host_done[0] = time.perf_counter()   # everything enqueued; the GPU may still be working
         return pack.read()
 
     def fence():
@@ -147,6 +150,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     scalars = run(args.steps, start=args.warmup)
+    host_ms = (host_done[0] - t0) / args.steps * 1e3
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -202,6 +206,7 @@ def main():
                                    f"vocab 3517, batch {bsz}/GPU, fp32, BatchNorm batch stats + dropout, Adam",
                        "global_batch": bsz * world, "parallelism": f"dp{world}",
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),
+                       "host_enqueue_ms_per_step": round(host_ms, 3),
                        "model_tflops": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12, 2),
                        "model_frac_of_fp32_mfma_peak": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12
                                                              / (FP32_MFMA_PEAK_TFLOPS * world), 4),

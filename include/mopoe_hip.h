@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 3
+#define MOPOE_ABI_VERSION 4
 
 /* error codes */
 #define MOPOE_OK 0
@@ -91,23 +91,37 @@ typedef struct {
  * Layers whose output grid cannot fill the chip split the tap x channel reduction across blocks, park
  * the partial sums there and finish (bias, mask, statistics) in a second small kernel. */
 size_t mopoe_conv_workspace_bytes(void);
+
+/* Launch plan of one conv op (NULL = the library's static heuristic).  Every plan computes the same sums in
+ * a different association order; the host mirror times the candidates the first time it meets a
+ * (op, geometry, fusion) triple during warm-up and keeps the fastest (mimic_amd/ops.py, MOPOE_AUTOTUNE).
+ *   fwd / dgrad: tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 output tile
+ *                split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction (needs workspace)
+ *   wgrad:       tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap)
+ *                split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp) */
+typedef struct {
+  int32_t tile;
+  int32_t split;
+} mopoe_conv_plan;
+
 int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y,
                    const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
-                   double* out_stats, void* workspace, size_t workspace_bytes, void* stream);
+                   double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* dx = d(conv)/d(input) applied to dy.  If relu_bn.mode != 0 the ReLU that fed the conv is inverted in
  * the epilogue, dx *= [bn(xin) > 0], and bwd_sums (optional) += {sum dx, sum dx*xhat} per input channel
  * (the two reductions BatchNorm's backward needs), xhat = (xin - mean) * rstd. */
 int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
-                     const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums,
+                     const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dwp[kh*kw][Cin][Cout] = d(conv)/d(weight); x is transformed by relu(bn(x)) when bn_in.mode != 0.
  * dwp is overwritten; when the pixel reduction is split across blocks the partial products are accumulated
  * with atomics into a zero-filled dwp: the library zero-fills it unless the caller states dwp_is_zero != 0
  * (callers that carve all weight gradients of a network out of one zeroed arena save ~100 memsets a step). */
 int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
-                     const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, void* stream);
+                     const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, const mopoe_conv_plan* plan, void* stream);
 
 /* ---- residual-block glue (HBM-bound elementwise + column reductions) -----------------------------
  * out = a * bn_s(s) + b * m           (ResidualBlocks.py:31-32,63-64,95-96,129-130 with the

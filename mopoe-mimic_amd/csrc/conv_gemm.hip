@@ -743,7 +743,8 @@ constexpr size_t WS_RECOMMENDED = 64u << 20;
 static int launch_gather(const float* X, const float* W, const float* bias, float* Y, const mopoe_conv_geom* g,
                          int dest_on_small, int Ck, int Cn, int w_nk, const mopoe_bn_ref* bn_in,
                          const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
-                         const float* xin, double* bwd_sums, void* ws, size_t ws_bytes, hipStream_t stream) {
+                         const float* xin, double* bwd_sums, const mopoe_conv_plan* plan, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
   GemmArgs a;
   a.X = X; a.W = W; a.Y = Y; a.bias = bias;
   a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;
@@ -793,6 +794,10 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   // a 128-wide tile would be half empty for the last 64 columns (Cout = 192, 320): use 64-wide tiles instead
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
+  if (plan && plan->tile >= 0) {
+    if (plan->tile > 2) { set_error("conv plan: tile %d (0 = 128x128, 1 = 256x64, 2 = 64x64)", plan->tile); return MOPOE_ERR_ARG; }
+    cfg = plan->tile;
+  }
   const int bm = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64), bn = cfg == 0 ? 128 : 64;
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
@@ -801,9 +806,16 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
-  if (ws && blocks < SPLIT_BLOCKS && iters * gbk >= 256) {
+  const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
+  if (plan && plan->split > 0) {
+    long ns = std::min<long>(plan->split, iters);
+    if (ns >= 2 && (!ws || (size_t)ns * per > ws_bytes)) {
+      set_error("conv plan: split %ld needs %zu workspace bytes (have %zu)", ns, (size_t)ns * per, ws ? ws_bytes : (size_t)0);
+      return MOPOE_ERR_ARG;
+    }
+    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
+  } else if (ws && blocks < SPLIT_BLOCKS && iters * gbk >= 256) {
     long ns = std::min<long>((SPLIT_TARGET + blocks - 1) / blocks, (long)iters * gbk / 128);
-    const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
     if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
@@ -847,7 +859,7 @@ extern "C" size_t mopoe_conv_workspace_bytes(void) { return WS_RECOMMENDED; }
 
 extern "C" int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const mopoe_conv_geom* g,
                               const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_geom(g)) return rc;
   if (!x || !wp || !y) { set_error("conv_fwd: null pointer"); return MOPOE_ERR_ARG; }
   const bool plain = (!bn_in || bn_in->mode == 0) && (!mask || mask->kind == 0);
@@ -858,23 +870,24 @@ extern "C" int mopoe_conv_fwd(const float* x, const float* wp, const float* bias
     return edge_reduce(x, wp, bias, y, g, g->Cin, (hipStream_t)stream);
   // Conv: output on the small grid.  ConvTranspose: output on the big grid (phases).
   return launch_gather(x, wp, bias, y, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask, out_stats,
-                       nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+                       nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,
-                                const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                const mopoe_bn_ref* relu_bn, const float* xin, double* bwd_sums,
+                                const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = validate_geom(g)) return rc;
   if (!dy || !wp || !dx) { set_error("conv_dgrad: null pointer"); return MOPOE_ERR_ARG; }
   if (g->transposed && g->Cout == 1 && (!relu_bn || relu_bn->mode == 0) && edge_supported(g, g->Cin, {wp, dx}))
     return edge_expand(dy, wp, dx, g, g->Cin, nullptr, (hipStream_t)stream);
   // input gradient of a Conv lives on the big grid (phases); of a ConvTranspose on the small grid.
   return launch_gather(dy, wp, nullptr, dx, g, g->transposed ? 1 : 0, g->Cout, g->Cin, /*w_nk=*/1, nullptr, nullptr,
-                       nullptr, relu_bn, xin, bwd_sums, workspace, workspace_bytes, (hipStream_t)stream);
+                       nullptr, relu_bn, xin, bwd_sums, plan, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_conv_geom* g,
-                                const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, void* stream_) {
+                                const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, const mopoe_conv_plan* plan,
+                                void* stream_) {
   if (int rc = validate_geom(g)) return rc;
   if (!x || !dy || !dwp) { set_error("conv_wgrad: null pointer"); return MOPOE_ERR_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
@@ -901,13 +914,14 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   a.dy_bytes = (unsigned)std::min<size_t>(db, 0x7fffffffu);
   if (rows_x >= (1ull << 31) || rows_dy >= (1ull << 31)) { set_error("wgrad: more than 2^31 rows"); return MOPOE_ERR_ARG; }
   const int taps = g->kh * g->kw;
-  const bool big = g->Cin > 64 && g->Cout > 64;
+  bool big = g->Cin > 64 && g->Cout > 64;
   const int T = big ? 128 : 64;
   const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
   a.nJ = nJ;
   const long tiles = (long)nI * nJ * taps;
   // split the pixel reduction until ~1024 blocks are in flight, keeping >= 8 K-chunks per block
   long split = (1024 + tiles - 1) / tiles;
+  if (plan && plan->split > 0) split = plan->split;
   const long max_split = (a.Ms + 8 * BK - 1) / (8 * BK);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;

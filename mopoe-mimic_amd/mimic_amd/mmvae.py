@@ -7,6 +7,7 @@ reparameterisation of the reference are ONE kernel here (ops.latent_fwd) and one
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from abc import ABC, abstractmethod
 from functools import lru_cache
@@ -19,6 +20,56 @@ import torch.nn as nn
 from . import ops
 
 MOD_SLOT = {"PA": 0, "Lateral": 1, "text": 2}
+
+# The three encoders (and, after the latent kernel, the three decoders) are independent: each modality's
+# networks run on their own HIP stream so that their small layers (8x8, 4x4, 1x1 grids and the text trunk,
+# none of which fills 256 CUs) overlap with the other modalities' work.  Autograd replays each network's
+# backward on the stream its forward ran on.  MOPOE_NET_STREAMS=0 keeps everything on the caller's stream.
+NET_STREAMS = os.environ.get("MOPOE_NET_STREAMS", "1") != "0"
+_net_streams: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
+
+
+class _ModalityLanes:
+    """fork(name) -> context running on that modality's stream after everything enqueued so far on the
+    caller's stream; join() makes the caller's stream wait for every forked lane."""
+
+    def __init__(self, device):
+        self.enabled = NET_STREAMS and device.type == "cuda"
+        self.used = []
+        if self.enabled:
+            self.device = device
+            self.main = torch.cuda.current_stream(device)
+            self.ev = torch.cuda.Event()
+            self.ev.record(self.main)
+
+    def fork(self, name):
+        if not self.enabled:
+            return contextlib.nullcontext()
+        key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), name)
+        if key not in _net_streams:
+            _net_streams[key] = torch.cuda.Stream(device=self.device)
+        s = _net_streams[key]
+        s.wait_event(self.ev)
+        self.used.append(s)
+        return torch.cuda.stream(s)
+
+    def share(self, *tensors):
+        """tensors made on the caller's stream that the lanes read (caching-allocator bookkeeping)"""
+        if self.enabled:
+            for t in tensors:
+                if t is not None:
+                    for s in _net_streams.values():
+                        t.record_stream(s)
+
+    def join(self, *tensors):
+        """caller's stream waits for the lanes; `tensors` were made on a lane and are read by the caller"""
+        if self.enabled:
+            for s in self.used:
+                self.main.wait_stream(s)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+            self.used = []
 
 
 def reweight_weights(w):
@@ -189,27 +240,43 @@ class VAEtrimodalMimic(BaseMMVae, nn.Module):
                    "joint_divergence": latents["_joint_divergence"].view(()),
                    "individual_divs": latents["_klds"], "dyn_prior": None}
         z = latents["_z"]
+        lanes = _ModalityLanes(z.device)
+        lanes.share(z)
+        dec = {}
+        for m_key, net in (("Lateral", self.decoder_lat), ("PA", self.decoder_pa), ("text", self.decoder_text)):
+            if m_key in self.modalities and input_batch[m_key] is not None:
+                with lanes.fork(m_key):
+                    dec[m_key] = net(None, z)
+        lanes.join(*[t for out in dec.values() for t in out if torch.is_tensor(t)])
         rec = {}
         for m_key in self.modalities:
-            if input_batch[m_key] is None:
+            if m_key not in dec:
                 continue
             if m_key == "Lateral":
-                rec[m_key] = self.lhood_lat(*self.decoder_lat(None, z))
+                rec[m_key] = self.lhood_lat(*dec[m_key])
             elif m_key == "PA":
-                rec[m_key] = self.lhood_pa(*self.decoder_pa(None, z))
+                rec[m_key] = self.lhood_pa(*dec[m_key])
             elif m_key == "text":
-                rec[m_key] = self.lhood_text(logits=self.decoder_text(None, z)[0])
+                rec[m_key] = self.lhood_text(logits=dec[m_key][0])
         results["rec"] = rec
         return results
 
     def encode(self, input_batch):
         latents = {}
+        lanes = None
         for name, enc in (("PA", self.encoder_pa), ("Lateral", self.encoder_lat), ("text", self.encoder_text)):
             if name in input_batch.keys():
-                latents[name] = list(enc(input_batch[name]))[:2]
+                x = input_batch[name]
+                if lanes is None:
+                    lanes = _ModalityLanes(x.device)
+                lanes.share(x)
+                with lanes.fork(name):
+                    latents[name] = list(enc(x))[:2]
             else:
                 latents[name + "_style"] = [None, None]
                 latents[name] = [None, None]
+        if lanes is not None:
+            lanes.join(*[t for v in latents.values() for t in v])
         return latents
 
     def get_random_styles(self, num_samples):

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -69,6 +69,13 @@ class Geom:
     ph: int
     pw: int
     transposed: bool
+
+    def __post_init__(self):
+        object.__setattr__(self, "_hash", hash((self.N, self.Hs, self.Ws, self.Hb, self.Wb, self.Cin, self.Cout, self.kh,
+                                                self.kw, self.sh, self.sw, self.ph, self.pw, self.transposed)))
+
+    def __hash__(self):   # Geoms key the plan / struct caches on every launch: hash once
+        return self._hash
 
     @property
     def in_shape(self):
@@ -214,6 +221,139 @@ def new_stats(n_channels: int, device) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # convolution family
 # ----------------------------------------------------------------------------------------------
+class _Plan(C.Structure):
+    """header: mopoe_conv_plan"""
+    _fields_ = [("tile", C.c_int32), ("split", C.c_int32)]
+
+
+# Launch plans.  The library has a static tile / split heuristic; the mirror can do better by measuring: the
+# first time a (op, geometry, fusion) triple is met (i.e. during the first warm-up step) every candidate plan
+# is launched a few times on scratch accumulators, timed with events on the current stream, and the fastest is
+# kept for the life of the process.  All plans compute the same sums (in a different association order).
+# MOPOE_AUTOTUNE=0 keeps the static heuristic (plan = NULL).
+AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") != "0"
+_TUNE_REPS = 4
+_plans = {}
+_GATHER_TILES = ((128, 128), (256, 64), (64, 64))
+_SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
+
+
+_forced_plan = None
+
+
+def clear_plans():
+    _plans.clear()
+
+
+class force_plan:
+    """context manager (tests): every conv op inside uses this (tile, split) instead of the tuned table"""
+
+    def __init__(self, tile: int, split: int):
+        self.plan = _Plan(tile, split)
+
+    def __enter__(self):
+        global _forced_plan
+        self.prev, _forced_plan = _forced_plan, self.plan
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_plan
+        _forced_plan = self.prev
+
+
+def plan_table():
+    """{(op, Geom, fusion flags): (tile, split) or None (static heuristic)} -- what the autotuner chose"""
+    return {k: (None if v is None else (v.tile, v.split)) for k, v in _plans.items()}
+
+
+def _gather_shape(kind: str, g: Geom):
+    """(rows per phase, phases, taps per phase, K channels, N channels) of the implicit GEMM (conv_gemm.hip)"""
+    ck, cn = (g.Cin, g.Cout) if kind == "fwd" else (g.Cout, g.Cin)
+    dest_on_small = (kind == "fwd") != bool(g.transposed)
+    if dest_on_small:
+        return g.N * g.Hs * g.Ws, 1, g.kh * g.kw, ck, cn
+    rows = g.N * -(-g.Hb // g.sh) * -(-g.Wb // g.sw)
+    return rows, g.sh * g.sw, max(1, (g.kh // g.sh) * (g.kw // g.sw)), ck, cn
+
+
+def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
+    if min(g.Cin, g.Cout) == 1:
+        return []   # image-side edge layers run on the streaming edge kernels: nothing to choose
+    rows, nphase, taps, ck, cn = _gather_shape(kind, g)
+    iters = taps * -(-ck // 16)
+    per = rows * nphase * cn * 4
+    cands = []
+    for tile, (bm, bn) in enumerate(_GATHER_TILES):
+        blocks = -(-rows // bm) * -(-cn // bn) * nphase
+        if tile == 1 and rows < 256:
+            continue
+        cands.append((tile, 1))
+        for s in _SPLITS:
+            if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
+                cands.append((tile, s))
+    return cands
+
+
+def _wgrad_candidates(g: Geom):
+    if min(g.Cin, g.Cout) == 1:
+        return []
+    ms = g.N * g.Hs * g.Ws
+    cands = []
+    for tile, tsz in ((0, 128), (2, 64)):
+        if tile == 0 and (g.Cin <= 64 or g.Cout <= 64):
+            continue
+        tiles = -(-g.Cin // tsz) * -(-g.Cout // tsz) * g.taps
+        seen = set()
+        for target in (256, 512, 768, 1024, 1536, 2048, 4096):
+            s = max(1, min(-(-target // tiles), -(-ms // 128)))
+            if s not in seen:
+                seen.add(s)
+                cands.append((tile, s))
+    return cands
+
+
+_scratch = {}
+
+
+def _scratch_like(t):
+    """zero-initialised stand-in for an accumulating output while candidates are being timed"""
+    if t is None:
+        return None
+    k = (t.dtype, t.numel(), t.device)
+    if k not in _scratch:
+        _scratch[k] = torch.zeros(t.numel(), dtype=t.dtype, device=t.device)
+    return _scratch[k]
+
+
+def _tuned_plan(key, cands_fn, launch):
+    """launch(plan_ref) enqueues the op once on scratch accumulators -> ctypes byref of the fastest plan (or None)"""
+    if _forced_plan is not None:
+        return C.byref(_forced_plan)
+    if key in _plans:
+        p = _plans[key]
+        return None if p is None else C.byref(p)
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return None
+    cands = cands_fn()
+    best, best_t = None, None
+    if len(cands) > 1:
+        for tile, split in cands:
+            plan = _Plan(tile, split)
+            ref = C.byref(plan)
+            launch(ref)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(_TUNE_REPS):
+                launch(ref)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t:
+                best, best_t = plan, t
+    _plans[key] = best
+    return None if best is None else C.byref(best)
+
+
 def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Optional[Mask] = None,
              out_stats=None):
     _dev(x, wp, bias, out_stats)
@@ -221,8 +361,17 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
     y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
     gc = g.c()
     ws, nbytes = _workspace(x.device)
-    _check(lib().mopoe_conv_fwd(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), _bn(bn_in), _mask(mask),
-                                _p(out_stats), _p(ws), C.c_size_t(nbytes), _stream()))
+    fn, stream = lib().mopoe_conv_fwd, _stream()
+    bnr, mr = _bn(bn_in), _mask(mask)
+
+    def launch(plan, stats=None):
+        _check(fn(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), bnr, mr, _p(stats), plan, _p(ws), C.c_size_t(nbytes),
+                  stream))
+
+    key = ("fwd", g, bn_in is not None, mask is not None, out_stats is not None)
+    plan = _tuned_plan(key, lambda: _gather_candidates("fwd", g, nbytes),
+                       lambda ref: launch(ref, _scratch_like(out_stats)))
+    launch(plan, out_stats)
     return y
 
 
@@ -232,8 +381,16 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
     dx = torch.empty(g.in_shape, dtype=torch.float32, device=dy.device)
     gc = g.c()
     ws, nbytes = _workspace(dy.device)
-    _check(lib().mopoe_conv_dgrad(_p(dy), _p(wp), _p(dx), C.byref(gc), _bn(relu_bn), _p(xin), _p(bwd_sums),
-                                  _p(ws), C.c_size_t(nbytes), _stream()))
+    fn, stream = lib().mopoe_conv_dgrad, _stream()
+    bnr = _bn(relu_bn)
+
+    def launch(plan, sums=None):
+        _check(fn(_p(dy), _p(wp), _p(dx), C.byref(gc), bnr, _p(xin), _p(sums), plan, _p(ws), C.c_size_t(nbytes), stream))
+
+    key = ("dgrad", g, relu_bn is not None, bwd_sums is not None)
+    plan = _tuned_plan(key, lambda: _gather_candidates("dgrad", g, nbytes),
+                       lambda ref: launch(ref, _scratch_like(bwd_sums)))
+    launch(plan, bwd_sums)
     return dx
 
 
@@ -244,8 +401,15 @@ def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
     dwp = out if out is not None else torch.empty((g.taps, g.Cin, g.Cout), dtype=torch.float32, device=x.device)
     assert tuple(dwp.shape) == (g.taps, g.Cin, g.Cout)
     gc = g.c()
-    _check(lib().mopoe_conv_wgrad(_p(x), _p(dy), _p(dwp), C.byref(gc), _bn(bn_in), C.c_int32(int(out is not None)),
-                                  _stream()))
+    fn, stream = lib().mopoe_conv_wgrad, _stream()
+    bnr = _bn(bn_in)
+
+    def launch(plan, dst, is_zero):
+        _check(fn(_p(x), _p(dy), _p(dst), C.byref(gc), bnr, C.c_int32(is_zero), plan, stream))
+
+    key = ("wgrad", g, bn_in is not None)
+    plan = _tuned_plan(key, lambda: _wgrad_candidates(g), lambda ref: launch(ref, _scratch_like(dwp), 1))
+    launch(plan, dwp, int(out is not None))
     return dwp
 
 

@@ -75,8 +75,10 @@ WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 
 
-def _side_stream(device, which=0):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
+def _side_stream(device, which=0, main=None):
+    """side stream `which` of the lane set that belongs to the stream `main` (each network stream has its own)"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which,
+           0 if main is None else main.cuda_stream)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
@@ -91,7 +93,7 @@ class _WgradLane:
         self.enabled = WGRAD_SIDE_STREAM and device.type == "cuda"
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
-            self.side = _side_stream(device, which)
+            self.side = _side_stream(device, which, self.main)
         self.keep = []   # tensors the side stream reads: kept alive until join()
 
     def run(self, fn, *inputs):

@@ -149,6 +149,55 @@ def test_conv_many_rows_tile_configs(name, g):
     test_conv_family(name, g)
 
 
+PLAN_GEOMS = [
+    ("enc_192to256", Geom(5, 4, 4, 8, 8, 192, 256, 4, 4, 2, 2, 1, 1, False)),
+    ("dec_128to64", Geom(3, 8, 8, 16, 16, 128, 64, 4, 4, 2, 2, 1, 1, True)),
+    ("linear_320to128", Geom(7, 1, 1, 1, 1, 320, 128, 1, 1, 1, 1, 0, 0, False)),
+    ("text_convT1d", Geom(3, 1, 16, 1, 32, 640, 512, 1, 4, 1, 2, 0, 1, True)),
+    ("ragged_c20", Geom(9, 3, 5, 6, 10, 36, 20, 4, 4, 2, 2, 1, 1, False)),
+    ("many_rows", Geom(3, 32, 32, 64, 64, 32, 192, 4, 4, 2, 2, 1, 1, False)),
+]
+
+
+@pytest.mark.parametrize("name,g", PLAN_GEOMS, ids=[n for n, _ in PLAN_GEOMS])
+def test_conv_every_launch_plan(name, g):
+    """mopoe_conv_plan: every tile x split the autotuner may pick computes the same result (fused epilogues on)."""
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(g.in_shape, generator=gen)
+    wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
+    bias = 0.1 * torch.randn(g.Cout, generator=gen)
+    dy = torch.randn(g.out_shape, generator=gen)
+    rows_in, rows_out = x.numel() // g.Cin, math.prod(g.out_shape[:3])
+    bn = make_bn(g.Cin, rows_in, 1, gen, x)
+    cmask = Mask((torch.rand(g.N, g.Cout, generator=gen) < 0.5).float() * 2, 1, rows_out // g.N)
+    st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+    y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref)
+    s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
+    dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
+    dw_ref = TB.conv_wgrad(x, dy, g, bn_in=bn)
+    xd, wd, dyd, bnd = x.to(DEV), wp.to(DEV), dy.to(DEV), to_dev(bn)
+    for tile in (0, 1, 2):
+        for split in (1, 2, 5, 16):
+            with ops.force_plan(tile, split):
+                st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                y = ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st)
+                s = torch.zeros(2, g.Cin, dtype=torch.float64, device=DEV)
+                dx = ops.conv_dgrad(dyd, wd, g, relu_bn=bnd, xin=xd, bwd_sums=s)
+            tag = f"plan/{name}/t{tile}s{split}"
+            check(f"{tag}/fwd", y, y_ref)
+            check(f"{tag}/fwd_stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
+            check(f"{tag}/dgrad", dx, dx_ref)
+            check(f"{tag}/dgrad_sums", s, s_ref, rtol=2e-4, atol_rel=2e-4)
+    for tile in (0, 2):
+        for split in (1, 3, 64):
+            with ops.force_plan(tile, split):
+                dw = ops.conv_wgrad(xd, dyd, g, bn_in=bnd)
+            check(f"plan/{name}/wgrad_t{tile}s{split}", dw, dw_ref, rtol=5e-4, atol_rel=5e-4)
+    with pytest.raises(ops.MopoeHipError):
+        with ops.force_plan(7, 1):
+            ops.conv_fwd(xd, wd, g)
+
+
 def test_conv_large_rows_splitk_and_big_tiles():
     """shapes of the C2 config's heaviest layers at reduced batch: exercises the 128x128 tiles and the
     split pixel reduction of wgrad."""
