@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <initializer_list>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mopoe {
@@ -54,7 +56,10 @@ constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x6
 #define GEMM_BK_BIG 16           // K-chunk of the 128x128 / 256x64 gather tiles
 #endif
 constexpr int MAX_BN_C = 1024;
-constexpr int LDS_PAD = 4;
+#ifndef GEMM_LDS_PAD
+#define GEMM_LDS_PAD 4
+#endif
+constexpr int LDS_PAD = GEMM_LDS_PAD;
 
 struct GemmArgs {
   const float* X;
@@ -80,11 +85,21 @@ struct GemmArgs {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0xFFFFFFF0u;  // voffset past every buffer: the hardware range check returns zeros
+// voffset past every buffer (operands are < 2 GiB, checked on the host): the hardware range check returns zeros.
+// 2^31 rather than ~0 so that voffset + soffset cannot wrap whichever of the two the range check includes.
+constexpr unsigned OOB = 0x80000000u;
 
 // 16-byte buffer load with hardware bounds check: no branch, no exec masking, zero for off >= bytes
 __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t srd, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// same with a wave-uniform byte offset in the instruction's scalar-offset slot: the per-iteration advance along K
+// costs one SALU add instead of one VALU add per load (VALU work does not hide beside fp32 MFMAs on this chip:
+// tests/tools/mfma_peak.hip measures +3.4 cycles per VALU op on a 64-cycle MFMA, from any wave of the SIMD)
+__device__ __forceinline__ float4 bld4s(__amdgpu_buffer_rsrc_t srd, unsigned byte_off, unsigned s_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, s_off, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
@@ -104,8 +119,14 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
-template <int BM, int BN, int WGM, int WGN, int GBK, bool VEC>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 4)) void gather_gemm_kernel(const GemmArgs a) {
+// SPEC fixes the three mode flags of the main loop at compile time (0 = all of them at run time):
+//   1 forward, plain operand   2 forward, BN+ReLU on the operand   3 input gradient (weights K-contiguous)
+// each with the fast K addressing (Ck a multiple of the chunk).  Without it the loop carries the untaken
+// variants' register copies and zero-fills as VALU work, which on this chip does not hide beside fp32 MFMAs.
+template <int BM, int BN, int WGM, int WGN, int GBK, bool VEC, int SPEC = 0>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : ((BM / WGM) * (BN / WGN) > 64 * 32 ? 2 : 4)))
+void gather_gemm_kernel(const GemmArgs a) {
+  static_assert(SPEC == 0 || VEC, "specialised loops exist for the vector path only");
   constexpr int NT = 64 * WGM * WGN;            // threads per block (4 or 8 waves)
   static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;     // wave tile
@@ -156,7 +177,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
   const int total = it_end > it_beg ? it_end - it_beg : 0;
 
   // ---- BN(+ReLU) table for the operand transform -----------------------------------------------
-  const bool xform = a.bn_in.mode != 0;
+  const bool xform = SPEC ? (SPEC == 2) : (a.bn_in.mode != 0);
+  const int w_nk = SPEC ? (SPEC == 3 ? 1 : 0) : a.w_nk;
   if (xform) {
     for (int c = tid; c < ((a.Ck + 3) & ~3); c += NT) {
       BnC k = BnC{0.f, 0.f, 0.f, 0.f};
@@ -183,6 +205,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
     cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
     rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
     if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+  }
+
+  // fast operand addressing (vector path, Ck a multiple of the K chunk): per-thread byte offsets are fixed per tap
+  // (A) or for the whole kernel (B); the K advance lives in the scalar offset of the buffer load
+  const bool fastk = SPEC ? true : (VEC && (a.Ck % GBK == 0));
+  unsigned voffB[B_PER_THR];
+#pragma unroll
+  for (int i = 0; i < B_PER_THR; ++i) voffB[i] = OOB;
+  if (w_nk == 0) {
+#pragma unroll
+    for (int i = 0; i < B_PER_THR_KN; ++i) {
+      const int k = tid / N4 + i * (NT / N4);
+      const int n = n0 + (tid % N4) * 4;
+      if ((k < GBK) & (n < a.Cn)) voffB[i] = ((unsigned)k * (unsigned)a.Cout_w + (unsigned)n) * 4u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < B_PER_THR_NK; ++i) {
+      const int n = n0 + trow + i * RPP;
+      if ((trow + i * RPP < BN) & (n < a.Cn)) voffB[i] = ((unsigned)n * (unsigned)a.Cout_w + (unsigned)kq * 4u) * 4u;
+    }
   }
 
   const long nMt = (a.rows_per_phase + BM - 1) / BM;
@@ -233,7 +276,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
           offA[i] = (unsigned)(rbase[i] + tapoff) * (unsigned)a.Ck * 4u;
         }
         offW = (unsigned)wtap * (unsigned)a.Cin_w * (unsigned)a.Cout_w * 4u;
+        if (fastk) {
+#pragma unroll
+          for (int i = 0; i < A_PER_THR; ++i) {
+            offA[i] = okA[i] ? offA[i] + (unsigned)kq * 16u : OOB;
+            pend_ok[i] = okA[i];
+          }
+        }
         tap_dirty = false;
+      }
+      if (fastk) {
+        const unsigned sA = (unsigned)ld_kc * 4u;
+        const unsigned sB = offW + (w_nk == 0 ? (unsigned)ld_kc * (unsigned)a.Cout_w * 4u : (unsigned)ld_kc * 4u);
+        if (xform) {
+          pend_sc = *reinterpret_cast<const float4*>(&bnS[ld_kc + kq * 4]);
+          pend_sh = *reinterpret_cast<const float4*>(&bnT[ld_kc + kq * 4]);
+        }
+        if constexpr (VEC) {
+#pragma unroll
+          for (int i = 0; i < A_PER_THR; ++i) ra[i] = bld4s(srdX, offA[i], sA);
+          if (w_nk == 0) {
+#pragma unroll
+            for (int i = 0; i < B_PER_THR_KN; ++i) rb[i] = bld4s(srdW, voffB[i], sB);
+          } else {
+#pragma unroll
+            for (int i = 0; i < B_PER_THR_NK; ++i) rb[i] = bld4s(srdW, voffB[i], sB);
+          }
+        }
+        ld_kc += GBK;
+        if (ld_kc >= nkc * GBK) { ld_kc = 0; ++ld_tap; tap_dirty = true; }
+        return;
       }
       const int kc = ld_kc;
       const int ck = kc + kq * 4;
@@ -257,7 +329,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
         pend_ok[i] = ok;
         ra[i] = v;
       }
-      if (a.w_nk == 0) {
+      if (w_nk == 0) {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_KN; ++i) {
           const int k = tid / N4 + i * (NT / N4);
@@ -291,7 +363,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
       if (ld_kc >= nkc * GBK) { ld_kc = 0; ++ld_tap; tap_dirty = true; }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
 #pragma unroll
       for (int i = 0; i < A_PER_THR; ++i) {
         const int r = trow + i * RPP;
@@ -309,7 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
         As[buf][kq * 4 + 2][r] = ra[i].z;
         As[buf][kq * 4 + 3][r] = ra[i].w;
       }
-      if (a.w_nk == 0) {
+      if (w_nk == 0) {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_KN; ++i) {
           const int k = tid / N4 + i * (NT / N4);
@@ -338,12 +411,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
 
     if (total > 0) {
       load_tiles(it_beg);
-      store_tiles(0);
+      store_tiles(std::integral_constant<int, 0>{});
     }
     __syncthreads();
 
-    for (int it = 0; it < total; ++it) {
-      const int cur = it & 1;
+    // one K chunk: prefetch the next chunk into registers, MFMA over the current LDS buffer, stage the prefetched
+    // chunk into the other buffer.  The buffer index is a compile-time constant (the loop below is unrolled by
+    // two) so that every LDS address is one per-thread base register plus an immediate.
+    auto chunk = [&](int it, auto curc) {
+      constexpr int cur = decltype(curc)::value;
       if (it + 1 < total) load_tiles(it_beg + it + 1);
 #ifdef GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(1);
@@ -365,9 +441,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? GEMM_MIN_WAVES : 
 #ifdef GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
-      if (it + 1 < total) store_tiles(cur ^ 1);
+      if (it + 1 < total) store_tiles(std::integral_constant<int, cur ^ 1>{});
       __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < total; it += 2) {
+      chunk(it, std::integral_constant<int, 0>{});
+      chunk(it + 1, std::integral_constant<int, 1>{});
     }
+    if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
     // ---- epilogue of this M tile ------------------------------------------------------------------------
     const float* __restrict__ xin = a.xin;
@@ -795,10 +877,12 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 2) { set_error("conv plan: tile %d (0 = 128x128, 1 = 256x64, 2 = 64x64)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 4) { set_error("conv plan: tile %d (0 = 128x128, 1 = 256x64, 2 = 64x64, 3 = 256x128, 4 = 128x64)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
+    if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the two extra tiles exist for the vector path only
   }
-  const int bm = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64), bn = cfg == 0 ? 128 : 64;
+  static const int TILE_BM[5] = {128, 256, 64, 256, 128}, TILE_BN[5] = {128, 64, 64, 128, 64};
+  const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
@@ -820,27 +904,37 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
-  long gx = std::min<long>(nMt, std::max<long>(1, PERSIST_BLOCKS / ((long)nNt * nphase * a.nsplit)));
+  const long persist = (cfg == 2 || cfg == 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS;   // 4-wave blocks: 3 per CU
+  long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
-    ProfScope prof(stream, flops, cfg == 0 ? PROF_GATHER128 : (cfg == 1 ? PROF_GATHER256x64 : PROF_GATHER64));
+    static const int TILE_PROF[5] = {PROF_GATHER128, PROF_GATHER256x64, PROF_GATHER64, PROF_GATHER256x128, PROF_GATHER128x64};
+    ProfScope prof(stream, flops, TILE_PROF[cfg]);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
+    // specialised main loops: vector path with Ck a multiple of the K chunk (every layer of the four networks
+    // except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
+    const int spec = (vec && Ck % 16 == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
+#define MOPOE_LAUNCH_TILE(BM_, BN_, WM_, WN_, THREADS_)                                                                        \
+  do {                                                                                                                          \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 1>), grid, dim3(THREADS_), 0, stream, a);      \
+    else if (spec == 2) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 2>), grid, dim3(THREADS_), 0, stream, a); \
+    else if (spec == 3) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 3>), grid, dim3(THREADS_), 0, stream, a); \
+    else hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 0>), grid, dim3(THREADS_), 0, stream, a);                \
+  } while (0)
     if (vec) {
-#if GEMM_8WAVES
-      if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 4, GEMM_BK_BIG, true>), grid, dim3(512), 0, stream, a);
-      else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 2, 16, true>), grid, dim3(512), 0, stream, a);
-#else
-      if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, true>), grid, dim3(256), 0, stream, a);
-      else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, true>), grid, dim3(256), 0, stream, a);
-#endif
-      else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, true>), grid, dim3(256), 0, stream, a);
+      if (cfg == 0) MOPOE_LAUNCH_TILE(128, 128, 2, 4, 512);
+      else if (cfg == 1) MOPOE_LAUNCH_TILE(256, 64, 4, 2, 512);
+      else if (cfg == 3) MOPOE_LAUNCH_TILE(256, 128, 4, 2, 512);
+      else if (cfg == 4) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 256);
+      else MOPOE_LAUNCH_TILE(64, 64, 2, 2, 256);
     } else {
       if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, false>), grid, dim3(256), 0, stream, a);
       else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, false>), grid, dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, false>), grid, dim3(256), 0, stream, a);
     }
+#undef MOPOE_LAUNCH_TILE
     if (int rc = check_launch("gather_gemm")) return rc;
     if (a.partial) {
       dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), EPI_MAX_BLOCKS_Y));

@@ -232,9 +232,9 @@ class _Plan(C.Structure):
 # kept for the life of the process.  All plans compute the same sums (in a different association order).
 # MOPOE_AUTOTUNE=0 keeps the static heuristic (plan = NULL).
 AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") != "0"
-_TUNE_REPS = 4
+_TUNE_REPS = 3
 _plans = {}
-_GATHER_TILES = ((128, 128), (256, 64), (64, 64))
+_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64))
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
 
 
@@ -261,6 +261,19 @@ class force_plan:
         _forced_plan = self.prev
 
 
+_plan_log = {}
+
+
+def plan_report():
+    """[(op, geometry, fusion flags, chosen (tile, split), its us, {candidate: us})] of every tuned triple"""
+    out = []
+    for key, timings in _plan_log.items():
+        p = _plans.get(key)
+        chosen = None if p is None else (p.tile, p.split)
+        out.append((key[0], key[1], key[2:], chosen, timings.get(chosen), timings))
+    return out
+
+
 def plan_table():
     """{(op, Geom, fusion flags): (tile, split) or None (static heuristic)} -- what the autotuner chose"""
     return {k: (None if v is None else (v.tile, v.split)) for k, v in _plans.items()}
@@ -285,8 +298,10 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
     cands = []
     for tile, (bm, bn) in enumerate(_GATHER_TILES):
         blocks = -(-rows // bm) * -(-cn // bn) * nphase
-        if tile == 1 and rows < 256:
+        if bm == 256 and rows < 256:
             continue
+        if tile >= 3 and (g.Cin % 4 or g.Cout % 4):
+            continue   # vector-path-only tiles
         cands.append((tile, 1))
         for s in _SPLITS:
             if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
@@ -335,22 +350,28 @@ def _tuned_plan(key, cands_fn, launch):
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return None
     cands = cands_fn()
-    best, best_t = None, None
+    best, timings = None, {}
     if len(cands) > 1:
-        for tile, split in cands:
-            plan = _Plan(tile, split)
+        def time_plan(plan, reps):
             ref = C.byref(plan)
-            launch(ref)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(_TUNE_REPS):
+            for _ in range(reps):
                 launch(ref)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if best_t is None or t < best_t:
-                best, best_t = plan, t
+            return e0.elapsed_time(e1) / reps * 1e3
+
+        plans = {c: _Plan(*c) for c in cands}
+        for c, plan in plans.items():          # pass 1: everything, briefly (first launch = warm-up)
+            launch(C.byref(plan))
+            timings[c] = time_plan(plan, _TUNE_REPS)
+        finalists = sorted(timings, key=timings.get)[:3]
+        for c in finalists:                    # pass 2: the three fastest, longer
+            timings[c] = time_plan(plans[c], 3 * _TUNE_REPS)
+        best = plans[min(finalists, key=timings.get)]
     _plans[key] = best
+    _plan_log[key] = timings
     return None if best is None else C.byref(best)
 
 
@@ -632,7 +653,8 @@ def prof_enable(on: bool):
 
 
 PROF_KINDS = ("gather_gemm_kernel<128,128,2,4,16>", "gather_gemm_kernel<64,64,2,2,16>", "wgrad_gemm_kernel<128,128>",
-              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,2,16>")
+              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,2,16>", "gather_gemm_kernel<256,128,4,2,16>",
+              "gather_gemm_kernel<128,64,2,2,16>")
 
 
 def prof_collect():

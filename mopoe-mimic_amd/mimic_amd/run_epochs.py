@@ -97,6 +97,8 @@ class ScalarPack:
             self.event.record()
 
     def read(self) -> typing.Dict[str, float]:
+        if self.host is None:   # nothing submitted yet
+            return {}
         if self.event is not None:
             self.event.synchronize()
         return dict(zip(self.names, self.host.tolist()))
