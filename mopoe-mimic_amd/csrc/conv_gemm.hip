@@ -421,6 +421,9 @@ void gather_gemm_kernel(const GemmArgs a) {
     auto chunk = [&](int it, auto curc) {
       constexpr int cur = decltype(curc)::value;
       if (it + 1 < total) load_tiles(it_beg + it + 1);
+      // the prefetch must be in flight during the whole MFMA block: without this fence the scheduler sinks the
+      // buffer loads down to their first use (the LDS stores below) and the wave sits out their full latency
+      __builtin_amdgcn_sched_barrier(0);
 #ifdef GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
@@ -561,11 +564,14 @@ struct WgradArgs {
   int atomic;        // 1: accumulate with atomics (split reduction)
   int vecI, vecJ;
   unsigned x_bytes, dy_bytes;   // operand sizes for the buffer descriptors (vector path)
+  int fast;          // 1: every 16-pixel K chunk is a run inside one image row, or whole rows of one image
   mopoe_bn_ref bn_in;
 };
 
-template <int BI, int BJ, bool VEC>
+// SPEC: 0 = mode flags at run time; 1 / 2 = fast pixel addressing without / with BN+ReLU on x (see gather_gemm_kernel)
+template <int BI, int BJ, bool VEC, int SPEC = 0>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
+  static_assert(SPEC == 0 || VEC, "specialised loops exist for the vector path only");
   constexpr int WI = BI / 2, WJ = BJ / 2;
   constexpr int TI = WI / 32, TJ = WJ / 32;
   constexpr int I_LD = BI + LDS_PAD, J_LD = BJ + LDS_PAD;
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
   const long mend = mbeg + a.chunk < a.Ms ? mbeg + a.chunk : a.Ms;
   const int total = (int)((mend - mbeg + BK - 1) / BK);
 
-  const bool xform = a.bn_in.mode != 0;
+  const bool xform = SPEC ? (SPEC == 2) : (a.bn_in.mode != 0);
+  const bool fast = SPEC ? true : (VEC && a.fast != 0);
   if (xform) {
     for (int c = tid; c < ((a.Cin + 3) & ~3); c += 256) {
       BnC k = BnC{0.f, 0.f, 0.f, 0.f};
@@ -629,7 +636,78 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
     sh4 = *reinterpret_cast<const float4*>(&bnT[cs]);
   }
 
+  // ---- fast pixel addressing ---------------------------------------------------------------------------------
+  // The order in which pixels are reduced is free, and when Ws is a multiple of the 16-pixel chunk (or divides it,
+  // with Hs*Ws a multiple of 16) every chunk is a run inside one image row (or whole rows of one image).  The
+  // chunk's origin (image, row, column) is then wave-uniform and advances with scalar adds; it enters the buffer
+  // loads through their scalar offset.  Each thread keeps constant byte offsets for its pixel slots; per chunk it
+  // only re-evaluates the bounds of the gathered operand.  The gathered operand's descriptor starts (ph*Wb + pw)
+  // rows BEFORE the tensor so that both offset parts stay non-negative; those rows are never touched (the bounds
+  // test sends them to the OOB offset).
+  const int rpc = a.Ws >= BK ? 1 : BK / a.Ws;              // image rows per chunk (fast path)
+  const int big_c = a.x_is_big ? a.Cin : a.Cout;           // channels of the gathered (big-grid) operand
+  const unsigned shift_rows = (unsigned)(a.ph * a.Wb + a.pw);
+  const unsigned shift_bytes = shift_rows * (unsigned)big_c * 4u;
+  const __amdgpu_buffer_rsrc_t srdBig = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)(a.x_is_big ? a.Xs : a.Dy) - shift_bytes), 0,
+      (int)((a.x_is_big ? a.x_bytes : a.dy_bytes) + shift_bytes), 0x00020000);
+  int f_ly[I_PER_THR], f_lx[I_PER_THR];          // lane part of the big-grid coordinates (may be negative)
+  unsigned f_vbig[I_PER_THR], f_vsmall_i[I_PER_THR], f_vsmall_j[I_PER_THR];
+  int f_slot[I_PER_THR];
+  int f_n = 0, f_qy = 0, f_qx = 0;               // chunk origin (wave-uniform)
+  unsigned f_m0 = 0;                             // first pixel of the chunk
+  if (fast) {
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const int p = tid / I4 + t * PPP;
+      const int pdy = a.Ws >= BK ? 0 : p / a.Ws, pqx = a.Ws >= BK ? p : p - (p / a.Ws) * a.Ws;
+      f_slot[t] = p;
+      f_ly[t] = pdy * a.sh + ky - a.ph;
+      f_lx[t] = pqx * a.sw + kx - a.pw;
+      const unsigned lane_rows = (unsigned)((f_ly[t] + a.ph) * a.Wb + (f_lx[t] + a.pw));
+      const int cbig = a.x_is_big ? ci : cj;
+      f_vbig[t] = (cbig < big_c) ? (lane_rows * (unsigned)big_c + (unsigned)cbig) * 4u : OOB;
+      f_vsmall_i[t] = (ci < a.Cin) ? ((unsigned)p * (unsigned)a.Cin + (unsigned)ci) * 4u : OOB;
+      f_vsmall_j[t] = (cj < a.Cout) ? ((unsigned)p * (unsigned)a.Cout + (unsigned)cj) * 4u : OOB;
+    }
+    const unsigned m0 = (unsigned)mbeg;
+    f_m0 = m0;
+    f_n = (int)(m0 / (unsigned)hw);
+    const unsigned rem = m0 - (unsigned)f_n * (unsigned)hw;
+    f_qy = (int)(rem / (unsigned)a.Ws);
+    f_qx = (int)(rem - (unsigned)f_qy * (unsigned)a.Ws);
+  }
+
   auto load_tiles = [&](int /*it*/) {
+    if (fast) {
+      if constexpr (VEC) {
+        const int nleft = (int)((unsigned)mend - f_m0);     // pixels of this split from the chunk origin on
+        const int s_by = f_qy * a.sh, s_bx = f_qx * a.sw;
+        const unsigned s_big = (unsigned)((f_n * a.Hb + s_by) * a.Wb + s_bx) * (unsigned)big_c * 4u;
+        const unsigned s_small_i = f_m0 * (unsigned)a.Cin * 4u, s_small_j = f_m0 * (unsigned)a.Cout * 4u;
+#pragma unroll
+        for (int t = 0; t < I_PER_THR; ++t) {
+          const bool inm = f_slot[t] < nleft;
+          const bool inb = ((unsigned)(s_by + f_ly[t]) < (unsigned)a.Hb) & ((unsigned)(s_bx + f_lx[t]) < (unsigned)a.Wb);
+          const unsigned vb = (inm & inb) ? f_vbig[t] : OOB;
+          if (a.x_is_big) {
+            ri[t] = bld4s(srdBig, vb, s_big);
+            rj[t] = bld4s(srdD, inm ? f_vsmall_j[t] : OOB, s_small_j);
+            pend_ok[t] = (inm & inb) & (ci < a.Cin);
+          } else {
+            ri[t] = bld4s(srdX, inm ? f_vsmall_i[t] : OOB, s_small_i);
+            rj[t] = bld4s(srdBig, vb, s_big);
+            pend_ok[t] = inm & (ci < a.Cin);
+          }
+        }
+        // next chunk (wave-uniform)
+        f_m0 += BK;
+        if (a.Ws >= BK) { f_qx += BK; if (f_qx >= a.Ws) { f_qx = 0; ++f_qy; } }
+        else f_qy += rpc;
+        if (f_qy >= a.Hs) { f_qy = 0; ++f_n; }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < I_PER_THR; ++t) {
       const bool inm = pm[t] < mend;
@@ -668,7 +746,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
     for (int t = 0; t < I_PER_THR; ++t) {
       const int p = tid / I4 + t * (256 / I4);
@@ -698,14 +777,15 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
 
   if (total > 0) {
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(std::integral_constant<int, 0>{});
   }
   __syncthreads();
 
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int it = 0; it < total; ++it) {
-    const int cur = it & 1;
+  auto chunk = [&](int it, auto curc) {
+    constexpr int cur = decltype(curc)::value;
     if (it + 1 < total) load_tiles(it + 1);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMA block (see gather_gemm_kernel)
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int k = kk * 2 + lhi;
@@ -720,9 +800,15 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
         for (int j = 0; j < TJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (it + 1 < total) store_tiles(cur ^ 1);
+    if (it + 1 < total) store_tiles(std::integral_constant<int, cur ^ 1>{});
     __syncthreads();
+  };
+  int it = 0;
+  for (; it + 1 < total; it += 2) {
+    chunk(it, std::integral_constant<int, 0>{});
+    chunk(it + 1, std::integral_constant<int, 1>{});
   }
+  if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -1007,6 +1093,9 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   a.x_bytes = (unsigned)std::min<size_t>(xb, 0x7fffffffu);
   a.dy_bytes = (unsigned)std::min<size_t>(db, 0x7fffffffu);
   if (rows_x >= (1ull << 31) || rows_dy >= (1ull << 31)) { set_error("wgrad: more than 2^31 rows"); return MOPOE_ERR_ARG; }
+  // fast pixel addressing: chunks of BK = 16 pixels never straddle an image row (or cover whole rows of one image)
+  const int hw_s = g->Hs * g->Ws;
+  a.fast = (vec && ((g->Ws % BK == 0) || (BK % g->Ws == 0 && hw_s % BK == 0))) ? 1 : 0;
   const int taps = g->kh * g->kw;
   bool big = g->Cin > 64 && g->Cout > 64;
   const int T = big ? 128 : 64;
@@ -1031,9 +1120,17 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   ProfScope prof(stream, flops, big ? PROF_WGRAD128 : PROF_WGRAD64);
   dim3 grid(nI * nJ, taps, (unsigned)split);
+  const int spec = a.fast ? (a.bn_in.mode != 0 ? 2 : 1) : 0;
   if (vec) {
-    if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, true>), grid, dim3(256), 0, stream, a);
+    if (big) {
+      if (spec == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 1>), grid, dim3(256), 0, stream, a);
+      else if (spec == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 2>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 0>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (spec == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, true, 1>), grid, dim3(256), 0, stream, a);
+      else if (spec == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, true, 2>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, true, 0>), grid, dim3(256), 0, stream, a);
+    }
   } else {
     if (big) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, false>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, false>), grid, dim3(256), 0, stream, a);

@@ -6,12 +6,12 @@ step this is not inflated by event overhead on 20 us kernels."""
 import os, sys, collections
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
+os.environ["MOPOE_WGRAD_STREAM"] = "0"
+os.environ["MOPOE_NET_STREAMS"] = "0"
 import torch
 from mimic_amd import ops, run_epochs as RE
 from mimic_amd.utils.experiment import HotPathExperiment, default_flags
 
-os.environ["MOPOE_WGRAD_STREAM"] = "0"
-os.environ["MOPOE_NET_STREAMS"] = "0"
 REP = 20
 calls = []
 orig = {}
