@@ -123,7 +123,10 @@ def main():
     exp = HotPathExperiment(flags)
     exp.mm_vae.to(device)
     exp.mm_vae.train()
-    exp.set_optimizer()
+    # single GPU: the whole step (forward, backward, Adam, scalar read-back) is captured into one hipGraph and
+    # replayed (run_epochs.GraphedTrainStep); with a gradient reducer the eager path overlaps RCCL with backward
+    use_graph = world == 1 and os.environ.get("MOPOE_GRAPH", "1") != "0"
+    exp.set_optimizer(capturable=use_graph)
     reducer = GradAllReducer(exp.mm_vae, world) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_parameters()
@@ -132,11 +135,15 @@ def main():
     torch.manual_seed(1234 + rank)
 
     host_done = [0.0]
+    graphed = RE.GraphedTrainStep(exp, batches[0], pack) if use_graph else None   # set-up: settles the launch plans, captures
 
-    def run(nsteps, start=0):
+    def run(nsteps, start=0, eager=False):
         for i in range(nsteps):
             b = batches[(start + i) % len(batches)]
-            RE.train_step(exp, ({k: v for k, v in b[0].items()}, None), reducer, pack)
+            if graphed is not None and not eager:
+                graphed(b)
+            else:
+                RE.train_step(exp, ({k: v for k, v in b[0].items()}, None), reducer, pack)
         host_done[0] = time.perf_counter()   # everything enqueued; the GPU may still be working
         return pack.read()
 
@@ -145,6 +152,18 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # device warm-up (not part of the W warm-up steps and not model work): a GPU that has just left idle needs
+    # sustained load before its clocks settle; a fresh process on an idle box otherwise times the ramp
+    spin_s = float(os.environ.get("MOPOE_BENCH_SPIN", "0"))
+    if spin_s > 0:
+        xs = torch.randn(4096, 4096, device=device)
+        t_end = time.perf_counter() + spin_s
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                xs = torch.tanh(xs @ xs * 1e-3)
+            torch.cuda.synchronize()
+        del xs
 
     run(args.warmup)
     fence()
@@ -165,7 +184,7 @@ def main():
         # second pass of the same steps with HIP events around every implicit-GEMM launch
         ops.prof_enable(True)
         nprof = min(args.steps, 5)
-        run(nprof, start=args.warmup)
+        run(nprof, start=args.warmup, eager=True)
         torch.cuda.synchronize()
         prof = ops.prof_collect()
         ops.prof_enable(False)
@@ -206,7 +225,7 @@ def main():
                                    f"vocab 3517, batch {bsz}/GPU, fp32, BatchNorm batch stats + dropout, Adam",
                        "global_batch": bsz * world, "parallelism": f"dp{world}",
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),
-                       "host_enqueue_ms_per_step": round(host_ms, 3),
+                       "host_enqueue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
                        "model_tflops": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12, 2),
                        "model_frac_of_fp32_mfma_peak": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12
                                                              / (FP32_MFMA_PEAK_TFLOPS * world), 4),

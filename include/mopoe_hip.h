@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 4
+#define MOPOE_ABI_VERSION 5
 
 /* error codes */
 #define MOPOE_OK 0
@@ -96,7 +96,7 @@ size_t mopoe_conv_workspace_bytes(void);
  * a different association order; the host mirror times the candidates the first time it meets a
  * (op, geometry, fusion) triple during warm-up and keeps the fastest (mimic_amd/ops.py, MOPOE_AUTOTUNE).
  *   fwd / dgrad: tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 output tile
- *                      (0, 1, 3: 8 waves per block; 2, 4: 4 waves)
+ *                      (0, 1, 3: 8 waves per block; 2, 4: 4 waves) | 5, 6 = tiles 2, 4 with a 32-deep K chunk
  *                split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction (needs workspace)
  *   wgrad:       tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap)
  *                split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp) */
@@ -154,7 +154,8 @@ int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float*
                        void* stream);
 
 /* running_mean/var momentum update for `n` BatchNorm layers in one launch (torch.nn.BatchNorm
- * train-mode side effect).  desc is a device array of n records {sums*, rmean*, rvar*, C, count}. */
+ * train-mode side effect).  desc is a HOST array of n records {sums*, rmean*, rvar*, C, count} (device pointers
+ * inside); it is copied into the kernel arguments before the call returns. */
 typedef struct {
   const double* sums;
   float* rmean;
@@ -232,9 +233,10 @@ int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int6
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
  * stream.  mopoe_prof_collect synchronises those events and fills, per kernel kind
  * (0 gather_gemm<128,128>, 1 gather_gemm<64,64>, 2 wgrad_gemm<128,128>, 3 wgrad_gemm<64,64>,
- * 4 gather_gemm<256,64>, 5 gather_gemm<256,128>, 6 gather_gemm<128,64>; arrays of MOPOE_PROF_KINDS entries), the number
- * of launches, their summed duration (ms) and their summed algorithmic FLOPs since the last collect. */
-#define MOPOE_PROF_KINDS 7
+ * 4 gather_gemm<256,64>, 5 gather_gemm<256,128>, 6 gather_gemm<128,64>, 7 gather_gemm<64,64,K32>, 8 gather_gemm<128,64,K32>;
+ * arrays of MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms) and their summed algorithmic
+ * FLOPs since the last collect. */
+#define MOPOE_PROF_KINDS 9
 int mopoe_prof_enable(int32_t on);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- profiling (api.hip) ----------------------------------------------------------------------------
-enum ProfKind { PROF_GATHER128 = 0, PROF_GATHER64 = 1, PROF_WGRAD128 = 2, PROF_WGRAD64 = 3, PROF_GATHER256x64 = 4, PROF_GATHER256x128 = 5, PROF_GATHER128x64 = 6, PROF_NKINDS = 7 };
+enum ProfKind { PROF_GATHER128 = 0, PROF_GATHER64 = 1, PROF_WGRAD128 = 2, PROF_WGRAD64 = 3, PROF_GATHER256x64 = 4, PROF_GATHER256x128 = 5, PROF_GATHER128x64 = 6, PROF_GATHER64_K32 = 7, PROF_GATHER128x64_K32 = 8, PROF_NKINDS = 9 };
 struct ProfScope {
   hipStream_t stream;
   int slot;

@@ -963,16 +963,17 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 4) { set_error("conv plan: tile %d (0 = 128x128, 1 = 256x64, 2 = 64x64, 3 = 256x128, 4 = 128x64)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 6) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..6)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
-    if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the two extra tiles exist for the vector path only
+    if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
+    if (cfg >= 5 && Ck % 32 != 0) cfg -= 3;         // 5, 6 = tiles 2, 4 with a 32-deep K chunk
   }
-  static const int TILE_BM[5] = {128, 256, 64, 256, 128}, TILE_BN[5] = {128, 64, 64, 128, 64};
+  static const int TILE_BM[7] = {128, 256, 64, 256, 128, 64, 128}, TILE_BN[7] = {128, 64, 64, 128, 64, 64, 64};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
-  const int gbk = (cfg == 0) ? GEMM_BK_BIG : 16;
+  const int gbk = cfg >= 5 ? 32 : 16;
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
@@ -990,31 +991,34 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
-  const long persist = (cfg == 2 || cfg == 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS;   // 4-wave blocks: 3 per CU
+  const long persist = (cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS;   // 4-wave blocks: 3 per CU
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
-    static const int TILE_PROF[5] = {PROF_GATHER128, PROF_GATHER256x64, PROF_GATHER64, PROF_GATHER256x128, PROF_GATHER128x64};
+    static const int TILE_PROF[7] = {PROF_GATHER128, PROF_GATHER256x64, PROF_GATHER64, PROF_GATHER256x128, PROF_GATHER128x64,
+                                     PROF_GATHER64_K32, PROF_GATHER128x64_K32};
     ProfScope prof(stream, flops, TILE_PROF[cfg]);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
     // specialised main loops: vector path with Ck a multiple of the K chunk (every layer of the four networks
     // except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
-    const int spec = (vec && Ck % 16 == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
-#define MOPOE_LAUNCH_TILE(BM_, BN_, WM_, WN_, THREADS_)                                                                        \
+    const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
+#define MOPOE_LAUNCH_TILE(BM_, BN_, WM_, WN_, BK_, THREADS_)                                                                    \
   do {                                                                                                                          \
-    if (spec == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 1>), grid, dim3(THREADS_), 0, stream, a);      \
-    else if (spec == 2) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 2>), grid, dim3(THREADS_), 0, stream, a); \
-    else if (spec == 3) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 3>), grid, dim3(THREADS_), 0, stream, a); \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, BK_, true, 1>), grid, dim3(THREADS_), 0, stream, a);      \
+    else if (spec == 2) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, BK_, true, 2>), grid, dim3(THREADS_), 0, stream, a); \
+    else if (spec == 3) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, BK_, true, 3>), grid, dim3(THREADS_), 0, stream, a); \
     else hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 0>), grid, dim3(THREADS_), 0, stream, a);                \
   } while (0)
     if (vec) {
-      if (cfg == 0) MOPOE_LAUNCH_TILE(128, 128, 2, 4, 512);
-      else if (cfg == 1) MOPOE_LAUNCH_TILE(256, 64, 4, 2, 512);
-      else if (cfg == 3) MOPOE_LAUNCH_TILE(256, 128, 4, 2, 512);
-      else if (cfg == 4) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 256);
-      else MOPOE_LAUNCH_TILE(64, 64, 2, 2, 256);
+      if (cfg == 0) MOPOE_LAUNCH_TILE(128, 128, 2, 4, 16, 512);
+      else if (cfg == 1) MOPOE_LAUNCH_TILE(256, 64, 4, 2, 16, 512);
+      else if (cfg == 3) MOPOE_LAUNCH_TILE(256, 128, 4, 2, 16, 512);
+      else if (cfg == 4) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 16, 256);
+      else if (cfg == 5) MOPOE_LAUNCH_TILE(64, 64, 2, 2, 32, 256);
+      else if (cfg == 6) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 32, 256);
+      else MOPOE_LAUNCH_TILE(64, 64, 2, 2, 16, 256);
     } else {
       if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, false>), grid, dim3(256), 0, stream, a);
       else if (cfg == 1) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, 16, false>), grid, dim3(256), 0, stream, a);

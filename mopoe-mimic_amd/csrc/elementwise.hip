@@ -198,8 +198,13 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* x, floa
 }
 
 // ---- running statistics ------------------------------------------------------------------------------------
-__global__ void bn_running_kernel(const mopoe_bn_running_desc* desc, float momentum) {
-  const mopoe_bn_running_desc d = desc[blockIdx.x];
+// the records travel in the kernel arguments (no device-side table: nothing to copy, nothing to keep alive, and the
+// launch can sit inside a hipGraph capture)
+constexpr int RUN_DESC_PER_LAUNCH = 32;
+struct RunDescPack { mopoe_bn_running_desc d[RUN_DESC_PER_LAUNCH]; };
+
+__global__ void bn_running_kernel(const RunDescPack pack, float momentum) {
+  const mopoe_bn_running_desc d = pack.d[blockIdx.x];
   const double inv = 1.0 / (double)d.count;
   const double unb = d.count > 1 ? (double)d.count / (double)(d.count - 1) : 1.0;
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
@@ -271,8 +276,18 @@ extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* 
 
 extern "C" int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_t n, float momentum, void* stream) {
   EW_ARGCHECK(desc && n > 0, "bn_running_update: bad arguments");
-  hipLaunchKernelGGL(bn_running_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, desc, momentum);
-  return check_launch("bn_running_update");
+  for (int32_t base = 0; base < n; base += RUN_DESC_PER_LAUNCH) {
+    const int32_t m = n - base < RUN_DESC_PER_LAUNCH ? n - base : RUN_DESC_PER_LAUNCH;
+    RunDescPack pack = {};
+    for (int32_t i = 0; i < m; ++i) {
+      pack.d[i] = desc[base + i];
+      EW_ARGCHECK(pack.d[i].sums && pack.d[i].rmean && pack.d[i].rvar && pack.d[i].C > 0 && pack.d[i].count > 0,
+                  "bn_running_update: bad record");
+    }
+    hipLaunchKernelGGL(bn_running_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, pack, momentum);
+    if (int rc = check_launch("bn_running_update")) return rc;
+  }
+  return MOPOE_OK;
 }
 
 extern "C" int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream) {

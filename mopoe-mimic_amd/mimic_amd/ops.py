@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -233,8 +233,13 @@ class _Plan(C.Structure):
 # MOPOE_AUTOTUNE=0 keeps the static heuristic (plan = NULL).
 AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") != "0"
 _TUNE_REPS = 3
+# Optional: leave the first N conv launches of the process on the static heuristic and start tuning afterwards
+# (a GPU that has just left idle ranks candidates differently from steady state).  Default 0 = tune at first use,
+# so that one warm-up step settles every plan.
+TUNE_AFTER_CALLS = int(os.environ.get("MOPOE_TUNE_AFTER_CALLS", "0"))
+_conv_calls = 0
 _plans = {}
-_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64))
+_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64))
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
 
 
@@ -302,6 +307,8 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
             continue
         if tile >= 3 and (g.Cin % 4 or g.Cout % 4):
             continue   # vector-path-only tiles
+        if tile >= 5 and ck % 32:
+            continue   # 32-deep K chunk
         cands.append((tile, 1))
         for s in _SPLITS:
             if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
@@ -349,9 +356,16 @@ def _tuned_plan(key, cands_fn, launch):
         return None if p is None else C.byref(p)
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return None
+    global _conv_calls
+    _conv_calls += 1
+    if _conv_calls <= TUNE_AFTER_CALLS:
+        return None   # still warming up: static heuristic, nothing cached
     cands = cands_fn()
     best, timings = None, {}
     if len(cands) > 1:
+        # candidates are timed alone on the device: work still queued on the other streams (the other modalities'
+        # networks, the weight-gradient lane) would otherwise run beside them and decide the ranking
+        torch.cuda.synchronize()
         def time_plan(plan, reps):
             ref = C.byref(plan)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -367,8 +381,8 @@ def _tuned_plan(key, cands_fn, launch):
             launch(C.byref(plan))
             timings[c] = time_plan(plan, _TUNE_REPS)
         finalists = sorted(timings, key=timings.get)[:3]
-        for c in finalists:                    # pass 2: the three fastest, longer
-            timings[c] = time_plan(plans[c], 3 * _TUNE_REPS)
+        for c in finalists:                    # pass 2: the three fastest, longer; best of three batches each
+            timings[c] = min(time_plan(plans[c], 2 * _TUNE_REPS) for _ in range(3))
         best = plans[min(finalists, key=timings.get)]
     _plans[key] = best
     _plan_log[key] = timings
@@ -489,31 +503,17 @@ def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, wan
     return dx, small[0], small[1], cs
 
 
-_run_desc_cache = {}
-
-
 def bn_running_update(entries: Sequence, momentum=0.1):
-    """entries: iterable of (sums double[2,C], running_mean, running_var, count).
-    The device-side descriptor table is cached by the pointers it holds: in steady state the caching
-    allocator hands the statistics arena the same address every step, so no host->device copy (which
-    would be a stream-synchronising pageable copy) happens inside the step."""
+    """entries: iterable of (sums double[2,C], running_mean, running_var, count).  One launch per 32 layers; the
+    records travel in the kernel arguments, so there is no device-side table to build or keep alive."""
     entries = list(entries)
     if not entries:
-        return None
-    key = tuple((s.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), c) for s, rm, rv, c in entries)
-    desc = _run_desc_cache.get(key)
-    if desc is None:
-        arr = (_RunDesc * len(entries))()
-        for i, (sums, rm, rv, count) in enumerate(entries):
-            _dev(sums, rm, rv)
-            arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        desc = host.to(entries[0][1].device)
-        if len(_run_desc_cache) > 256:
-            _run_desc_cache.clear()
-        _run_desc_cache[key] = desc
-    _check(lib().mopoe_bn_running_update(_p(desc), len(entries), C.c_float(momentum), _stream()))
-    return desc
+        return
+    arr = (_RunDesc * len(entries))()
+    for i, (sums, rm, rv, count) in enumerate(entries):
+        _dev(sums, rm, rv)
+        arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
+    _check(lib().mopoe_bn_running_update(arr, len(entries), C.c_float(momentum), _stream()))
 
 
 def colsum(x):
@@ -654,7 +654,7 @@ def prof_enable(on: bool):
 
 PROF_KINDS = ("gather_gemm_kernel<128,128,2,4,16>", "gather_gemm_kernel<64,64,2,2,16>", "wgrad_gemm_kernel<128,128>",
               "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,2,16>", "gather_gemm_kernel<256,128,4,2,16>",
-              "gather_gemm_kernel<128,64,2,2,16>")
+              "gather_gemm_kernel<128,64,2,2,16>", "gather_gemm_kernel<64,64,2,2,32>", "gather_gemm_kernel<128,64,2,2,32>")
 
 
 def prof_collect():

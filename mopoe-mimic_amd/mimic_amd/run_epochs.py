@@ -93,14 +93,20 @@ class ScalarPack:
         self.host.copy_(packed, non_blocking=True)
         self.names = names
         if self.device.type == "cuda":
-            self.event = torch.cuda.Event()
-            self.event.record()
+            if torch.cuda.is_current_stream_capturing():
+                self.event = None       # a captured step is read back after a stream synchronise (GraphedTrainStep)
+                self.stream = torch.cuda.current_stream()
+            else:
+                self.event = torch.cuda.Event()
+                self.event.record()
 
     def read(self) -> typing.Dict[str, float]:
         if self.host is None:   # nothing submitted yet
             return {}
         if self.event is not None:
             self.event.synchronize()
+        elif getattr(self, "stream", None) is not None:
+            self.stream.synchronize()
         return dict(zip(self.names, self.host.tolist()))
 
 
@@ -116,6 +122,51 @@ def train_step(exp, batch, reducer=None, pack: typing.Optional[ScalarPack] = Non
     if pack is not None:
         pack.submit(routine, reducer)
     return routine
+
+
+class GraphedTrainStep:
+    """train_step captured once into a hipGraph and replayed: the ~750 kernel launches, stream forks/joins, the
+    fused Adam and the scalar read-back of one step cost the host one graph launch instead of ~15 ms of Python.
+
+    Usage:  step = GraphedTrainStep(exp, example_batch, pack);  step(batch)  ->  scalars via pack.read().
+    Needs exp.set_optimizer(capturable=True).  The batch is copied into static input tensors; shapes are fixed.
+    Launch plans must be settled before the capture, so `warmup` eager steps run first (they do update the model,
+    exactly like the same number of ordinary train steps).  BatchNorm's num_batches_tracked is advanced on the host
+    per replay.  Single-process only: with a gradient reducer the eager path (which overlaps RCCL with backward) is used.
+    """
+
+    def __init__(self, exp, example_batch, pack: typing.Optional[ScalarPack] = None, warmup: int = 2):
+        from .layout import BnParams
+        self.exp, self.pack = exp, pack
+        dev = exp.flags.device
+        self.static = {k: v.to(dev).clone() for k, v in example_batch[0].items()}
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                train_step(exp, (dict(self.static), None), None, pack)
+        self.stream.synchronize()
+        bns = [m for m in exp.mm_vae.modules() if isinstance(m, BnParams)]
+        before = [m.pending_batches for m in bns]
+        self.graph = torch.cuda.CUDAGraph()
+        exp.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.routine = train_step(exp, (dict(self.static), None), None, pack)
+        # (the capture only records: parameters, optimiser state and running statistics are untouched by it)
+        self._bn_bump = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
+        for m, d in self._bn_bump:
+            m.pending_batches -= d
+
+    def __call__(self, batch):
+        for k, v in batch[0].items():
+            self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        if self.pack is not None and self.pack.device.type == "cuda":   # read-back fence on the replaying stream
+            self.pack.event = torch.cuda.Event()
+            self.pack.event.record()
+        for m, d in self._bn_bump:
+            m.pending_batches += d
+        return self.routine
 
 
 def train(exp, train_loader, reducer=None, max_steps=None):

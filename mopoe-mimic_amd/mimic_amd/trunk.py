@@ -72,6 +72,7 @@ class MaskSource:
 # optimizer), so they are launched on a second HIP stream: on the deep / 1-D layers, whose grids cannot fill 256
 # CUs, the wgrad kernels then run concurrently with the dgrad / BatchNorm-backward chain instead of after it.
 WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
+LANES = os.environ.get("MOPOE_LANES", "0,1").split(",")   # 0 = weight gradients, 1 = projection-shortcut branch
 _side_streams = {}
 
 
@@ -90,7 +91,11 @@ class _WgradLane:
     backward), which is independent of the main conv1 -> conv2 chain until the residual mix."""
 
     def __init__(self, device, which=0):
-        self.enabled = WGRAD_SIDE_STREAM and device.type == "cuda"
+        # not while a hipGraph is being captured: lanes forked from the per-modality streams (themselves forked from
+        # the capture stream) make hipStreamEndCapture crash on ROCm 7.2; the graph gets its parallelism from the
+        # modality streams alone
+        self.enabled = (WGRAD_SIDE_STREAM and device.type == "cuda" and str(which) in LANES
+                        and not torch.cuda.is_current_stream_capturing())
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
             self.side = _side_stream(device, which, self.main)

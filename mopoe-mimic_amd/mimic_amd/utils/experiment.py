@@ -69,13 +69,16 @@ class HotPathExperiment:
     def set_model(self):
         return VAEtrimodalMimic(self.flags, self.modalities, self.subsets)
 
-    def set_optimizer(self):
+    def set_optimizer(self, capturable: bool = False):
         params = list(self.mm_vae.parameters())
         # same Adam arithmetic as the reference's optim.Adam (experiment.py:171-178); the fused
-        # multi-tensor implementation updates all ~370 tensors in a handful of launches
+        # multi-tensor implementation updates all ~370 tensors in a handful of launches.
+        # capturable: step counters live on the device so that the step can sit inside a hipGraph
+        # (run_epochs.GraphedTrainStep)
         fused = all(p.is_cuda for p in params)
         self.optimizer = optim.Adam(params, lr=self.flags.initial_learning_rate,
-                                    betas=(self.flags.beta_1, self.flags.beta_2), fused=fused)
+                                    betas=(self.flags.beta_1, self.flags.beta_2), fused=fused,
+                                    capturable=bool(capturable and fused))
 
     def set_rec_weights(self):
         f = self.flags

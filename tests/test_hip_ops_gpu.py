@@ -176,7 +176,7 @@ def test_conv_every_launch_plan(name, g):
     dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
     dw_ref = TB.conv_wgrad(x, dy, g, bn_in=bn)
     xd, wd, dyd, bnd = x.to(DEV), wp.to(DEV), dy.to(DEV), to_dev(bn)
-    for tile in (0, 1, 2, 3, 4):
+    for tile in range(7):
         for split in (1, 2, 5, 16):
             with ops.force_plan(tile, split):
                 st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
