@@ -123,9 +123,10 @@ def main():
     exp = HotPathExperiment(flags)
     exp.mm_vae.to(device)
     exp.mm_vae.train()
-    # single GPU: the whole step (forward, backward, Adam, scalar read-back) is captured into one hipGraph and
-    # replayed (run_epochs.GraphedTrainStep); with a gradient reducer the eager path overlaps RCCL with backward
-    use_graph = world == 1 and os.environ.get("MOPOE_GRAPH", "1") != "0"
+    # the step is captured into hipGraphs and replayed (run_epochs.GraphedTrainStep): one graph for the whole step
+    # at N = 1; at N > 1 forward + backward and Adam are two graphs with the RCCL all-reduce of the gradient arenas
+    # (never captured) between them.  MOPOE_GRAPH=0 selects the eager step (RCCL overlapped with backward).
+    use_graph = os.environ.get("MOPOE_GRAPH", "1") != "0"
     exp.set_optimizer(capturable=use_graph)
     reducer = GradAllReducer(exp.mm_vae, world) if world > 1 else None
     if reducer is not None:
@@ -135,7 +136,22 @@ def main():
     torch.manual_seed(1234 + rank)
 
     host_done = [0.0]
-    graphed = RE.GraphedTrainStep(exp, batches[0], pack) if use_graph else None   # set-up: settles the launch plans, captures
+    trace = int(os.environ.get("MOPOE_BENCH_TRACE", "0"))
+    hist = []
+    graphed = None
+    if use_graph:   # set-up (not a timed or warm-up step): settles the launch plans, captures the step
+        try:
+            graphed = RE.GraphedTrainStep(exp, batches[0], pack, reducer)
+        except Exception as e:   # e.g. a runtime that refuses the capture: the eager step is always available
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
+            graphed, use_graph = None, False
+            exp.set_optimizer(capturable=False)
+    if world > 1:   # every rank must take the same path (graphed ranks issue their collectives at different points)
+        ok = torch.tensor([1.0 if graphed is not None else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if use_graph and ok.item() < 0.5:
+            graphed, use_graph = None, False
+            exp.set_optimizer(capturable=False)
 
     def run(nsteps, start=0, eager=False):
         for i in range(nsteps):
@@ -144,6 +160,12 @@ def main():
                 graphed(b)
             else:
                 RE.train_step(exp, ({k: v for k, v in b[0].items()}, None), reducer, pack)
+            if trace == 2:            # debugging aid without synchronisation: losses kept on the device
+                r = graphed.routine if (graphed is not None and not eager) else None
+                if r is not None:
+                    hist.append(r["total_loss"].detach().clone())
+            elif trace and rank == 0:   # debugging aid: synchronises every step
+                print(f"[trace] step {start + i}: total_loss {pack.read().get('total_loss')}", flush=True)
         host_done[0] = time.perf_counter()   # everything enqueued; the GPU may still be working
         return pack.read()
 
@@ -215,6 +237,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.config)
 
+    if hist and rank == 0:
+        print("[trace] per-step local losses:", [round(float(h), 1) for h in hist], flush=True)
     if rank == 0:
         line = {
             "metric": "samples/sec", "value": round(value, 2), "unit": "samples/sec", "n_gpus": world,

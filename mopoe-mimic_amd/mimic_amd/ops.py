@@ -237,6 +237,7 @@ _TUNE_REPS = 3
 # (a GPU that has just left idle ranks candidates differently from steady state).  Default 0 = tune at first use,
 # so that one warm-up step settles every plan.
 TUNE_AFTER_CALLS = int(os.environ.get("MOPOE_TUNE_AFTER_CALLS", "0"))
+TUNE_ALPHA = float(os.environ.get("MOPOE_TUNE_ALPHA", "1.0"))
 _conv_calls = 0
 _plans = {}
 _GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64))
@@ -296,11 +297,11 @@ def _gather_shape(kind: str, g: Geom):
 
 def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
     if min(g.Cin, g.Cout) == 1:
-        return []   # image-side edge layers run on the streaming edge kernels: nothing to choose
+        return {}   # image-side edge layers run on the streaming edge kernels: nothing to choose
     rows, nphase, taps, ck, cn = _gather_shape(kind, g)
     iters = taps * -(-ck // 16)
     per = rows * nphase * cn * 4
-    cands = []
+    cands = {}   # (tile, split) -> fraction of the chip the launch occupies
     for tile, (bm, bn) in enumerate(_GATHER_TILES):
         blocks = -(-rows // bm) * -(-cn // bn) * nphase
         if bm == 256 and rows < 256:
@@ -309,18 +310,19 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
             continue   # vector-path-only tiles
         if tile >= 5 and ck % 32:
             continue   # 32-deep K chunk
-        cands.append((tile, 1))
+        cap = 512 if tile in (0, 1, 3) else 768          # blocks resident at once (8-wave / 4-wave tiles)
+        cands[(tile, 1)] = min(1.0, blocks / cap)
         for s in _SPLITS:
             if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
-                cands.append((tile, s))
+                cands[(tile, s)] = min(1.0, blocks * s / cap)
     return cands
 
 
 def _wgrad_candidates(g: Geom):
     if min(g.Cin, g.Cout) == 1:
-        return []
+        return {}
     ms = g.N * g.Hs * g.Ws
-    cands = []
+    cands = {}
     for tile, tsz in ((0, 128), (2, 64)):
         if tile == 0 and (g.Cin <= 64 or g.Cout <= 64):
             continue
@@ -330,7 +332,7 @@ def _wgrad_candidates(g: Geom):
             s = max(1, min(-(-target // tiles), -(-ms // 128)))
             if s not in seen:
                 seen.add(s)
-                cands.append((tile, s))
+                cands[(tile, s)] = min(1.0, tiles * s / 768)
     return cands
 
 
@@ -377,13 +379,17 @@ def _tuned_plan(key, cands_fn, launch):
             return e0.elapsed_time(e1) / reps * 1e3
 
         plans = {c: _Plan(*c) for c in cands}
+        # objective: duration x (alpha + (1 - alpha) x fraction of the chip occupied).  alpha = 1 ranks by latency
+        # alone; below 1 a launch that leaves CUs free for the other modalities' branches of the step graph is
+        # charged less for its duration
+        score = lambda c: timings[c] * (TUNE_ALPHA + (1.0 - TUNE_ALPHA) * cands[c])
         for c, plan in plans.items():          # pass 1: everything, briefly (first launch = warm-up)
             launch(C.byref(plan))
             timings[c] = time_plan(plan, _TUNE_REPS)
-        finalists = sorted(timings, key=timings.get)[:3]
-        for c in finalists:                    # pass 2: the three fastest, longer; best of three batches each
+        finalists = sorted(timings, key=score)[:3]
+        for c in finalists:                    # pass 2: the three best, longer; best of three batches each
             timings[c] = min(time_plan(plans[c], 2 * _TUNE_REPS) for _ in range(3))
-        best = plans[min(finalists, key=timings.get)]
+        best = plans[min(finalists, key=score)]
     _plans[key] = best
     _plan_log[key] = timings
     return None if best is None else C.byref(best)

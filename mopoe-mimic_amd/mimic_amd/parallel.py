@@ -33,6 +33,7 @@ class GradAllReducer:
         self.module, self.world_size = module, world_size
         self._pending = []       # (work handle, arena)
         self._avg = None
+        self._deferred = None    # list of arenas while a step is being captured into a hipGraph (no collectives inside)
         if world_size > 1:
             backend = dist.get_backend()
             self._avg = dist.ReduceOp.AVG if backend == "nccl" else None   # gloo has no AVG: SUM then scale
@@ -70,7 +71,38 @@ class GradAllReducer:
         ``zero_grad(set_to_none=True)``, so reducing the arena in place reduces ``param.grad``."""
         if self.world_size <= 1:
             return
+        if self._deferred is not None:
+            self._deferred.append(arena)
+            return
         self._pending.append((self._launch(arena), arena))
+
+    # ---- graphed steps (run_epochs.GraphedTrainStep): forward + backward live in one hipGraph, the collectives run
+    # eagerly between that graph and the optimiser graph, on the arenas' fixed addresses
+    def begin_deferred(self):
+        self._deferred = []
+
+    def end_deferred(self):
+        arenas, self._deferred = self._deferred, None
+        return arenas
+
+    def reduce_static(self, arenas, outside, flat):
+        """all-reduce the recorded arenas in place and, through the preallocated staging buffer `flat`, the
+        gradients `outside` them"""
+        works = [self._launch(a) for a in arenas]
+        if outside:
+            torch.cat([g.reshape(-1) for g in outside], out=flat)
+            works.append(self._launch(flat))
+        for w in works:
+            w.wait()
+        if self._avg is None:
+            for a in arenas:
+                a.div_(self.world_size)
+            if outside:
+                flat.div_(self.world_size)
+        off = 0
+        for g in outside:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
 
     def all_reduce_grads(self):
         """Wait for the per-network collectives started during backward and finish averaging; then reduce, in

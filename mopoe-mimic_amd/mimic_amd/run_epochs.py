@@ -125,34 +125,63 @@ def train_step(exp, batch, reducer=None, pack: typing.Optional[ScalarPack] = Non
 
 
 class GraphedTrainStep:
-    """train_step captured once into a hipGraph and replayed: the ~750 kernel launches, stream forks/joins, the
-    fused Adam and the scalar read-back of one step cost the host one graph launch instead of ~15 ms of Python.
+    """train_step captured once into hipGraphs and replayed: the ~750 kernel launches, stream forks/joins, the
+    fused Adam and the scalar read-back of one step cost the host one graph launch instead of ~15 ms of Python,
+    and the three modalities' branches of the graph run side by side on the device.
 
-    Usage:  step = GraphedTrainStep(exp, example_batch, pack);  step(batch)  ->  scalars via pack.read().
+    Usage:  step = GraphedTrainStep(exp, example_batch, pack[, reducer]);  step(batch);  scalars via pack.read().
     Needs exp.set_optimizer(capturable=True).  The batch is copied into static input tensors; shapes are fixed.
     Launch plans must be settled before the capture, so `warmup` eager steps run first (they do update the model,
     exactly like the same number of ordinary train steps).  BatchNorm's num_batches_tracked is advanced on the host
-    per replay.  Single-process only: with a gradient reducer the eager path (which overlaps RCCL with backward) is used.
+    per replay.
+
+    Data parallel (reducer given): no collective is captured.  Graph A = forward + backward, then the gradient
+    arenas are all-reduced eagerly at their fixed addresses (RCCL), then graph B = Adam; the scalar pack is
+    averaged and read back eagerly.
     """
 
-    def __init__(self, exp, example_batch, pack: typing.Optional[ScalarPack] = None, warmup: int = 2):
+    def __init__(self, exp, example_batch, pack: typing.Optional[ScalarPack] = None,
+                 reducer: typing.Optional["GradAllReducer"] = None, warmup: int = 2):
         from .layout import BnParams
         self.exp, self.pack = exp, pack
+        self.reducer = reducer if (reducer is not None and reducer.world_size > 1) else None
         dev = exp.flags.device
         self.static = {k: v.to(dev).clone() for k, v in example_batch[0].items()}
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
-                train_step(exp, (dict(self.static), None), None, pack)
+                train_step(exp, (dict(self.static), None), self.reducer, pack)
         self.stream.synchronize()
         bns = [m for m in exp.mm_vae.modules() if isinstance(m, BnParams)]
         before = [m.pending_batches for m in bns]
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_opt = None
         exp.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.routine = train_step(exp, (dict(self.static), None), None, pack)
-        # (the capture only records: parameters, optimiser state and running statistics are untouched by it)
+        if self.reducer is None:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.routine = train_step(exp, (dict(self.static), None), None, pack)
+        else:
+            # other threads keep making HIP calls here (the process group's watchdog polls events): they must not
+            # invalidate the capture, hence thread_local
+            self.reducer.begin_deferred()
+            try:
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                    self.routine = basic_routine_epoch(exp, (dict(self.static), None))
+                    exp.optimizer.zero_grad(set_to_none=True)
+                    self.routine["total_loss"].backward()
+            finally:
+                self.arenas = self.reducer.end_deferred()
+            ranges = [(a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()) for a in self.arenas]
+            self.outside = [p.grad for p in exp.mm_vae.parameters()
+                            if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]
+            n_out = sum(g.numel() for g in self.outside)
+            self.flat = torch.empty(n_out, dtype=torch.float32, device=dev) if n_out else None
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, stream=self.stream, pool=self.graph.pool(),
+                                  capture_error_mode="thread_local"):
+                exp.optimizer.step()
+        # (a capture only records: parameters, optimiser state and running statistics are untouched by it)
         self._bn_bump = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
         for m, d in self._bn_bump:
             m.pending_batches -= d
@@ -161,7 +190,12 @@ class GraphedTrainStep:
         for k, v in batch[0].items():
             self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
-        if self.pack is not None and self.pack.device.type == "cuda":   # read-back fence on the replaying stream
+        if self.reducer is not None:
+            self.reducer.reduce_static(self.arenas, self.outside, self.flat)
+            self.graph_opt.replay()
+            if self.pack is not None:
+                self.pack.submit(self.routine, self.reducer)
+        elif self.pack is not None and self.pack.device.type == "cuda":   # read-back fence on the replaying stream
             self.pack.event = torch.cuda.Event()
             self.pack.event.record()
         for m, d in self._bn_bump:
