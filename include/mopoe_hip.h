@@ -97,6 +97,7 @@ size_t mopoe_conv_workspace_bytes(void);
  * (op, geometry, fusion) triple during warm-up and keeps the fastest (mimic_amd/ops.py, MOPOE_AUTOTUNE).
  *   fwd / dgrad: tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 output tile
  *                      (0, 1, 3: 8 waves per block; 2, 4: 4 waves) | 5, 6 = tiles 2, 4 with a 32-deep K chunk
+ *                      | 7 = 128x128 with 4 waves per block
  *                split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction (needs workspace)
  *   wgrad:       tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap)
  *                split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp) */
@@ -231,12 +232,15 @@ int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int6
 
 /* ---- profiling support for bench.py ------------------------------------------------------------------
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
- * stream.  mopoe_prof_collect synchronises those events and fills, per kernel kind
- * (0 gather_gemm<128,128>, 1 gather_gemm<64,64>, 2 wgrad_gemm<128,128>, 3 wgrad_gemm<64,64>,
- * 4 gather_gemm<256,64>, 5 gather_gemm<256,128>, 6 gather_gemm<128,64>, 7 gather_gemm<64,64,K32>, 8 gather_gemm<128,64,K32>;
- * arrays of MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms) and their summed algorithmic
- * FLOPs since the last collect. */
-#define MOPOE_PROF_KINDS 9
+ * stream.  mopoe_prof_collect synchronises those events and fills, per kernel instantiation (arrays of
+ * MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms) and their summed algorithmic FLOPs
+ * since the last collect.  Kinds (the host mirror turns them into the template names rocprofv3 prints):
+ *   0..31  gather_gemm_kernel, vector path: tile * 4 + spec (tile as in mopoe_conv_plan; spec 0 = run-time modes,
+ *          1 forward, 2 forward with BN+ReLU on the operand, 3 input gradient)
+ *   32..34 gather_gemm_kernel, scalar path: 128x128, 256x64, 64x64
+ *   36..41 wgrad_gemm_kernel, vector path: (128x128 ? 0 : 3) + spec (0 run-time modes, 1 plain, 2 BN+ReLU on x)
+ *   42..43 wgrad_gemm_kernel, scalar path: 128x128, 64x64 */
+#define MOPOE_PROF_KINDS 44
 int mopoe_prof_enable(int32_t on);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

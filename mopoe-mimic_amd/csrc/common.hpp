@@ -58,7 +58,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- profiling (api.hip) ----------------------------------------------------------------------------
-enum ProfKind { PROF_GATHER128 = 0, PROF_GATHER64 = 1, PROF_WGRAD128 = 2, PROF_WGRAD64 = 3, PROF_GATHER256x64 = 4, PROF_GATHER256x128 = 5, PROF_GATHER128x64 = 6, PROF_GATHER64_K32 = 7, PROF_GATHER128x64_K32 = 8, PROF_NKINDS = 9 };
+// one kind per kernel instantiation, so that the names bench.py reports are the names rocprofv3 prints:
+//   gather, vector path:  tile * 4 + spec            (tile 0..7, spec 0..3)        kinds  0..31
+//   gather, scalar path:  32 + {0: 128x128, 1: 256x64, 2: 64x64}                   kinds 32..34
+//   wgrad,  vector path:  36 + (128x128 ? 0 : 3) + spec   (spec 0..2)              kinds 36..41
+//   wgrad,  scalar path:  42 + (128x128 ? 0 : 1)                                   kinds 42..43
+enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {
   hipStream_t stream;
   int slot;

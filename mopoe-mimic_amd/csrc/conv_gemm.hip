@@ -963,17 +963,17 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 6) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..6)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 7) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..7)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
-    if (cfg >= 5 && Ck % 32 != 0) cfg -= 3;         // 5, 6 = tiles 2, 4 with a 32-deep K chunk
+    if ((cfg == 5 || cfg == 6) && Ck % 32 != 0) cfg -= 3;   // 5, 6 = tiles 2, 4 with a 32-deep K chunk
   }
-  static const int TILE_BM[7] = {128, 256, 64, 256, 128, 64, 128}, TILE_BN[7] = {128, 64, 64, 128, 64, 64, 64};
+  static const int TILE_BM[8] = {128, 256, 64, 256, 128, 64, 128, 128}, TILE_BN[8] = {128, 64, 64, 128, 64, 64, 64, 128};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
-  const int gbk = cfg >= 5 ? 32 : 16;
+  const int gbk = (cfg == 5 || cfg == 6) ? 32 : 16;
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
@@ -997,13 +997,11 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
-    static const int TILE_PROF[7] = {PROF_GATHER128, PROF_GATHER256x64, PROF_GATHER64, PROF_GATHER256x128, PROF_GATHER128x64,
-                                     PROF_GATHER64_K32, PROF_GATHER128x64_K32};
-    ProfScope prof(stream, flops, TILE_PROF[cfg]);
-    dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
-    // specialised main loops: vector path with Ck a multiple of the K chunk (every layer of the four networks
-    // except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
     const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
+    ProfScope prof(stream, flops, vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg);
+    dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
+    // specialised main loops (spec != 0): vector path with Ck a multiple of the K chunk (every layer of the four
+    // networks except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
 #define MOPOE_LAUNCH_TILE(BM_, BN_, WM_, WN_, BK_, THREADS_)                                                                    \
   do {                                                                                                                          \
     if (spec == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, BK_, true, 1>), grid, dim3(THREADS_), 0, stream, a);      \
@@ -1018,6 +1016,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
       else if (cfg == 4) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 16, 256);
       else if (cfg == 5) MOPOE_LAUNCH_TILE(64, 64, 2, 2, 32, 256);
       else if (cfg == 6) MOPOE_LAUNCH_TILE(128, 64, 2, 2, 32, 256);
+      else if (cfg == 7) MOPOE_LAUNCH_TILE(128, 128, 2, 2, 16, 256);
       else MOPOE_LAUNCH_TILE(64, 64, 2, 2, 16, 256);
     } else {
       if (cfg == 0) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, GEMM_BK_BIG, false>), grid, dim3(256), 0, stream, a);
@@ -1122,9 +1121,9 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
     if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
-  ProfScope prof(stream, flops, big ? PROF_WGRAD128 : PROF_WGRAD64);
-  dim3 grid(nI * nJ, taps, (unsigned)split);
   const int spec = a.fast ? (a.bn_in.mode != 0 ? 2 : 1) : 0;
+  ProfScope prof(stream, flops, vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1));
+  dim3 grid(nI * nJ, taps, (unsigned)split);
   if (vec) {
     if (big) {
       if (spec == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 1>), grid, dim3(256), 0, stream, a);

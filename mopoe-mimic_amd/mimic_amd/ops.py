@@ -240,7 +240,7 @@ TUNE_AFTER_CALLS = int(os.environ.get("MOPOE_TUNE_AFTER_CALLS", "0"))
 TUNE_ALPHA = float(os.environ.get("MOPOE_TUNE_ALPHA", "1.0"))
 _conv_calls = 0
 _plans = {}
-_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64))
+_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128))
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
 
 
@@ -308,7 +308,7 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
             continue
         if tile >= 3 and (g.Cin % 4 or g.Cout % 4):
             continue   # vector-path-only tiles
-        if tile >= 5 and ck % 32:
+        if tile in (5, 6) and ck % 32:
             continue   # 32-deep K chunk
         cap = 512 if tile in (0, 1, 3) else 768          # blocks resident at once (8-wave / 4-wave tiles)
         cands[(tile, 1)] = min(1.0, blocks / cap)
@@ -658,9 +658,26 @@ def prof_enable(on: bool):
     _check(lib().mopoe_prof_enable(int(on)))
 
 
-PROF_KINDS = ("gather_gemm_kernel<128,128,2,4,16>", "gather_gemm_kernel<64,64,2,2,16>", "wgrad_gemm_kernel<128,128>",
-              "wgrad_gemm_kernel<64,64>", "gather_gemm_kernel<256,64,4,2,16>", "gather_gemm_kernel<256,128,4,2,16>",
-              "gather_gemm_kernel<128,64,2,2,16>", "gather_gemm_kernel<64,64,2,2,32>", "gather_gemm_kernel<128,64,2,2,32>")
+_TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16", "256, 128, 4, 2, 16", "128, 64, 2, 2, 16",
+                   "64, 64, 2, 2, 32", "128, 64, 2, 2, 32", "128, 128, 2, 2, 16")
+
+
+def _prof_kind_names():
+    """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
+    names = [None] * 44
+    for tile, tt in enumerate(_TILE_TEMPLATES):
+        for spec in range(4):
+            names[tile * 4 + spec] = f"gather_gemm_kernel<{tt}, true, {spec}>"
+    for i, tt in enumerate(("128, 128, 2, 2, 16", "256, 64, 4, 1, 16", "64, 64, 2, 2, 16")):
+        names[32 + i] = f"gather_gemm_kernel<{tt}, false, 0>"
+    for i, tt in enumerate(("128, 128", "64, 64")):
+        for spec in range(3):
+            names[36 + 3 * i + spec] = f"wgrad_gemm_kernel<{tt}, true, {spec}>"
+        names[42 + i] = f"wgrad_gemm_kernel<{tt}, false, 0>"
+    return names
+
+
+PROF_KINDS = _prof_kind_names()
 
 
 def prof_collect():
@@ -668,4 +685,4 @@ def prof_collect():
     k = len(PROF_KINDS)
     n, ms, fl = (C.c_int64 * k)(), (C.c_double * k)(), (C.c_double * k)()
     _check(lib().mopoe_prof_collect(n, ms, fl))
-    return {name: (n[i], ms[i], fl[i]) for i, name in enumerate(PROF_KINDS)}
+    return {name: (n[i], ms[i], fl[i]) for i, name in enumerate(PROF_KINDS) if name is not None and n[i] > 0}

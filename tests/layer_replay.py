@@ -69,14 +69,19 @@ def main():
             fn(*a, **k)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / REP * 1e3
-        rows.append((us * len(lst) / 1e3, len(lst), us, name + fused, g, flops(name, g)))
+        kind = name.split("_")[1]
+        flags = {"fwd": (k.get("bn_in") is not None, k.get("mask") is not None, k.get("out_stats") is not None),
+                 "dgrad": (k.get("relu_bn") is not None, k.get("bwd_sums") is not None),
+                 "wgrad": (k.get("bn_in") is not None,)}[kind]
+        plan = ops.plan_table().get((kind, g) + flags)
+        rows.append((us * len(lst) / 1e3, len(lst), us, name + fused + f" {plan}", g, flops(name, g)))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows); totfl = sum(r[5] * r[1] for r in rows)
     print(f"conv ops total {tot:.3f} ms/step, {totfl/1e9:.1f} GF/step, {totfl / (tot * 1e-3) / 1e12:.1f} TF/s average")
     cum = 0.0
     for t, c, us, name, g, fl in rows:
         cum += t
-        print(f"{t:7.3f} ms/step (cum {cum:6.2f}) x{c:2d} {us:8.1f}us {fl / (us * 1e-6) / 1e12:7.1f}TF/s  {name:18s} "
+        print(f"{t:7.3f} ms/step (cum {cum:6.2f}) x{c:2d} {us:8.1f}us {fl / (us * 1e-6) / 1e12:7.1f}TF/s  {name:28s} "
               f"{'T' if g.transposed else 'C'} {g.Cin:4d}->{g.Cout:4d} k{g.kh}x{g.kw} s{g.sw} p{g.pw} small{g.Hs}x{g.Ws} big{g.Hb}x{g.Wb}")
     agg = collections.defaultdict(lambda: [0.0, 0.0])
     for t, c, us, name, g, fl in rows:
