@@ -86,7 +86,7 @@ def main():
     agg = collections.defaultdict(lambda: [0.0, 0.0])
     for t, c, us, name, g, fl in rows:
         net = "text(1-D)" if (g.kh == 1 and g.kw == 4) or (g.Hs == 1 and g.Ws > 1) else "image+linear"
-        a = agg[(net, name.split("+")[0])]; a[0] += t; a[1] += fl * c
+        a = agg[(net, name.split("+")[0].split(" ")[0])]; a[0] += t; a[1] += fl * c
     for k, (t, fl) in sorted(agg.items()):
         print(f"{k}: {t:.3f} ms/step, {fl / (t * 1e-3) / 1e12:.1f} TF/s")
 
