@@ -10,6 +10,11 @@ for p in (REPO, os.path.join(REPO, "mopoe-mimic_amd"), os.path.join(REPO, "oracl
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The launch-plan tuner times ~30 candidates per (op, geometry) at first use: fine once per training process, slow over
+# the hundreds of geometries the suite touches.  Tests run on the library's static heuristic unless they opt in
+# (`tuned_plans` fixture); every plan the tuner can pick is forced and checked in test_conv_every_launch_plan.
+os.environ.setdefault("MOPOE_AUTOTUNE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -33,3 +38,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def tuned_plans(monkeypatch):
+    """run this test with the launch-plan tuner on (as bench.py and real training do)"""
+    from mimic_amd import ops
+    monkeypatch.setattr(ops, "AUTOTUNE", True)
+    ops.clear_plans()
+    yield
+    ops.clear_plans()
