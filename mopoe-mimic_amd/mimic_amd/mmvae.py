@@ -209,7 +209,7 @@ class BaseMMVae(ABC, nn.Module):
         style_latents = self.get_random_styles(num_samples)
         out = {}
         for key, (mu, logvar) in latent_distributions.items():
-            eps = torch.randn_like(mu)
+            eps = self._draw_eps(mu.shape[0], mu.shape[1], mu.device)   # (tests inject the noise through eps_source)
             content = eps * torch.exp(0.5 * logvar) + mu  # off the training path: plain torch on device
             out[key] = self.generate_from_latents({"content": content, "style": style_latents})
         return out
