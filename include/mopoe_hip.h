@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 5
+#define MOPOE_ABI_VERSION 6
 
 /* error codes */
 #define MOPOE_OK 0
@@ -221,6 +221,16 @@ int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32
 /* dlogp = -g[0]/norm at [r, ids[r]], zero elsewhere (dlogp is overwritten). */
 int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t rows, int32_t V, float norm,
                         float* dlogp, void* stream);
+
+/* Per-row log-probabilities for the importance-sampled likelihood estimator (reference:
+ * mimic/utils/likelihood.py:119-120,185-186 `likelihood.log_prob(x_rep).view(B*K, -1).sum(dim=1)` on a target repeated
+ * K times).  Row r of the decoder output is scored against target row r % target_rows; nothing is repeated in memory.
+ *   laplace: out[r] = sum_j ( -log(2 scale) - |x[r % B][j] - x_hat[r][j]| / scale )      x_hat [rows, per_row], x [B, per_row]
+ *   token:   out[r] = sum_l logp[r][l][ids[r % B][l]]                                    logp [rows, L, V], ids [B, L] (float) */
+int mopoe_laplace_logprob_rows(const float* x_hat, const float* x, int64_t rows, int64_t per_row,
+                               int64_t target_rows, float scale, float* out, void* stream);
+int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, int32_t L, int32_t V,
+                             int64_t target_rows, float* out, void* stream);
 
 /* ---- embedding (word_encoding/mmvae_text_enc.py:27-28,73) ------------------------------------------
  * out[r, :] = table[(int)ids[r], :]; backward scatter-adds into dtable (overwritten), skipping

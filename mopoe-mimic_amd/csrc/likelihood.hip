@@ -187,6 +187,41 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* ids, co
   }
 }
 
+// ---- per-row log-probabilities (importance-sampled likelihood estimator) -----------------------------------------
+// out[r] = sum_j ( -log(2b) - |x[(r % B) P + j] - xhat[r P + j]| / b ): one block per row; the K repeats of the
+// target are an index (r % B), not a materialised [K,B,...] copy
+__global__ __launch_bounds__(256) void laplace_logprob_rows_kernel(const float* xh, const float* x, long P, long B, float inv_scale,
+                                                                 float log2b, float* out, int vec) {
+  const long r = blockIdx.x;
+  const float* a = xh + r * P;
+  const float* b = x + (r % B) * P;
+  float acc = 0.f;
+  if (vec) {
+    const long n4 = P >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+      acc += fabsf(v.x - u.x) + fabsf(v.y - u.y) + fabsf(v.z - u.z) + fabsf(v.w - u.w);
+    }
+  } else {
+    for (long i = threadIdx.x; i < P; i += 256) acc += fabsf(b[i] - a[i]);
+  }
+  const double s = block_sum_256(acc);
+  if (threadIdx.x == 0) out[r] = (float)(-(double)P * (double)log2b - s * (double)inv_scale);
+}
+
+// out[r] = sum_l logp[(r L + l) V + ids[(r % B) L + l]]
+__global__ __launch_bounds__(256) void token_logprob_rows_kernel(const float* logp, const float* ids, int L, int V, long B, float* out) {
+  const long r = blockIdx.x;
+  float acc = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    int id = (int)ids[(r % B) * L + l];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    acc += logp[(r * L + l) * (long)V + id];
+  }
+  const double s = block_sum_256(acc);
+  if (threadIdx.x == 0) out[r] = (float)s;
+}
+
 static int stream_grid(long n, int per_thread) {
   long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (blocks < 1) blocks = 1;
@@ -252,6 +287,27 @@ extern "C" int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t row
   if (hipMemsetAsync(dlogp, 0, sizeof(float) * (size_t)rows * V, st) != hipSuccess) { set_error("token_nll_bwd memset failed"); return MOPOE_ERR_LAUNCH; }
   hipLaunchKernelGGL(token_nll_bwd_kernel, dim3(stream_grid(rows, 1)), dim3(256), 0, st, ids, g, (long)rows, V, 1.0f / norm, dlogp);
   return check_launch("token_nll_bwd");
+}
+
+extern "C" int mopoe_laplace_logprob_rows(const float* x_hat, const float* x, int64_t rows, int64_t per_row, int64_t target_rows,
+                                          float scale, float* out, void* stream) {
+  if (!x_hat || !x || !out || rows <= 0 || per_row <= 0 || target_rows <= 0 || scale <= 0.f || rows > 0x7fffffffL) {
+    set_error("laplace_logprob_rows: bad arguments"); return MOPOE_ERR_ARG;
+  }
+  const int vec = (per_row % 4 == 0) && ((reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  hipLaunchKernelGGL(laplace_logprob_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x_hat, x, (long)per_row,
+                     (long)target_rows, 1.0f / scale, logf(2.0f * scale), out, vec);
+  return check_launch("laplace_logprob_rows");
+}
+
+extern "C" int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, int32_t L, int32_t V, int64_t target_rows,
+                                        float* out, void* stream) {
+  if (!logp || !ids || !out || rows <= 0 || L <= 0 || V <= 0 || target_rows <= 0 || rows > 0x7fffffffL) {
+    set_error("token_logprob_rows: bad arguments"); return MOPOE_ERR_ARG;
+  }
+  hipLaunchKernelGGL(token_logprob_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logp, ids, L, V,
+                     (long)target_rows, out);
+  return check_launch("token_logprob_rows");
 }
 
 extern "C" int mopoe_embedding_fwd(const float* ids, const float* table, float* out, int64_t rows, int32_t V, int32_t D,

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -633,6 +633,29 @@ def token_nll_bwd(ids, g, shape, norm):
     _check(lib().mopoe_token_nll_bwd(_p(ids), _p(g), C.c_int64(ids.numel()), shape[-1], C.c_float(norm),
                                      _p(dlogp), _stream()))
     return dlogp
+
+
+def laplace_logprob_rows(x_hat, target, scale: float):
+    """x_hat [R, ...], target [B, ...] with R a multiple of B -> float [R]: row r scored against target row r % B"""
+    _dev(x_hat, target)
+    rows, tb = x_hat.shape[0], target.shape[0]
+    per_row = x_hat.numel() // rows
+    assert target.numel() // tb == per_row and rows % tb == 0
+    out = torch.empty(rows, dtype=torch.float32, device=x_hat.device)
+    _check(lib().mopoe_laplace_logprob_rows(_p(x_hat), _p(target), C.c_int64(rows), C.c_int64(per_row), C.c_int64(tb),
+                                            C.c_float(scale), _p(out), _stream()))
+    return out
+
+
+def token_logprob_rows(logp, ids):
+    """logp [R, L, V] log-probabilities, ids [B, L] float token ids, R a multiple of B -> float [R]"""
+    _dev(logp, ids)
+    rows, L, V = logp.shape
+    tb = ids.shape[0]
+    assert ids.shape[1] == L and rows % tb == 0
+    out = torch.empty(rows, dtype=torch.float32, device=logp.device)
+    _check(lib().mopoe_token_logprob_rows(_p(logp), _p(ids), C.c_int64(rows), L, V, C.c_int64(tb), _p(out), _stream()))
+    return out
 
 
 def embedding_fwd(ids, table):

@@ -67,6 +67,12 @@ class FusedLaplace:
         """sum(log_prob(target)) / norm_value as one HIP reduction (0-dim tensor)."""
         return -_LaplaceNll.apply(self.loc, target, self.scale_value, float(norm_value)).view(())
 
+    def log_prob_rows(self, target):
+        """log_prob summed per row of loc [R, ...] against target [B, ...] repeated R/B times (row r <-> r % B):
+        what the likelihood estimator needs from `log_prob(x_rep).view(R, -1).sum(dim=1)`, without the repeat or
+        the elementwise tensor (evaluation only: no gradient)."""
+        return ops.laplace_logprob_rows(self.loc.detach().contiguous(), target.contiguous(), self.scale_value)
+
 
 class FusedOneHotCategorical:
     """Stand-in for torch.distributions.OneHotCategorical(logits=log-probabilities [B,L,V])."""
@@ -90,6 +96,11 @@ class FusedOneHotCategorical:
     def summed_log_prob(self, target_ids, norm_value):
         """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised)."""
         return -_TokenNll.apply(self.logits, target_ids, float(norm_value)).view(())
+
+    def log_prob_rows(self, target_ids):
+        """per-row sum over the sequence of the picked log-probabilities: logits [R,L,V] against float ids [B,L]
+        repeated R/B times (row r <-> r % B); evaluation only."""
+        return ops.token_logprob_rows(self.logits.detach().contiguous(), target_ids.contiguous())
 
 
 def get_likelihood(name: str):

@@ -397,6 +397,31 @@ def gen_g3(run_epochs):
     return store
 
 
+def gen_g4(run_epochs):
+    """Importance-sampled likelihood estimates (mimic/evaluation/eval_metrics/likelihood.py:17-96) of the tiny model:
+    the reference's calc_log_likelihood_batch for four subsets with K = 6, plus the noise it drew."""
+    from mimic.evaluation.eval_metrics.likelihood import calc_log_likelihood_batch
+    cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=4)
+    sd = R.init_state(cfg, seed=31)
+    batch, _ = R.synthetic_batch(cfg, 4, seed=9)
+    exp = build_reference(cfg, sd)
+    exp.mm_vae.eval()
+    k = 6
+    store = {"cfg": np.array([64, 8, 4, 4, 50, 4]), "seed_weights": np.array(31), "seed_batch": np.array(9), "K": np.array(k)}
+    with torch.no_grad():
+        lat = exp.mm_vae.inference({m: v.clone() for m, v in batch.items()})
+        for s_key in ("PA", "text", "Lateral_text", "Lateral_PA_text"):
+            seed = 500 + len(s_key)
+            torch.manual_seed(seed)
+            ll = calc_log_likelihood_batch(exp, lat, s_key, exp.subsets[s_key], {m: v.clone() for m, v in batch.items()},
+                                           num_imp_samples=k)
+            torch.manual_seed(seed)   # utils.reparameterize draws std.data.new(std.size()).normal_() on [K,B,D]
+            store[f"{s_key}/eps"] = torch.empty(k, 4, cfg.class_dim).normal_().numpy()
+            for m_key, v in ll.items():
+                store[f"{s_key}/{m_key}"] = np.array(float(v))
+    return store
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -415,6 +440,7 @@ def main():
         "g1_c1": lambda: gen_g1(run_epochs, 64, 64, 8, 64),
         "g2_edges": lambda: gen_g2(run_epochs),
         "g3_traj": lambda: gen_g3(run_epochs),
+        "g4_likelihood": lambda: gen_g4(run_epochs),
     }
     for name, job in jobs.items():
         if args.only and name not in args.only:

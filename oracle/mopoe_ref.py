@@ -419,6 +419,66 @@ def forward_step(cfg: Cfg, sd, batch: Dict[str, torch.Tensor], eps: torch.Tensor
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# importance-sampled log-likelihood estimator (evaluation)
+# --------------------------------------------------------------------------------------------
+LOG2PI = float(math.log(2.0 * math.pi))
+
+
+def log_mean_exp(x, dim=1):
+    """mimic/utils/likelihood.py:41-53."""
+    m = torch.max(x, dim=dim, keepdim=True)[0]
+    return m + torch.log(torch.mean(torch.exp(x - m), dim=dim, keepdim=True))
+
+
+def gaussian_log_pdf(x, mu, logvar):
+    """mimic/utils/likelihood.py:56-67."""
+    return torch.sum(-0.5 * LOG2PI - logvar / 2. - torch.pow(x - mu, 2) / (2. * torch.exp(logvar)), dim=1)
+
+
+def unit_gaussian_log_pdf(x):
+    """mimic/utils/likelihood.py:70-80."""
+    return torch.sum(-0.5 * LOG2PI - torch.pow(x, 2) / 2., dim=1)
+
+
+def likelihood_estimates(cfg: Cfg, sd, batch, subset_posterior, eps, scale: float = 0.75):
+    """calc_log_likelihood_batch (mimic/evaluation/eval_metrics/likelihood.py:17-96) for
+    factorized_representation=False, followed by log_marginal_estimate / log_joint_estimate
+    (mimic/utils/likelihood.py:83-147,150-220).
+
+    subset_posterior = (mu, logvar) [B,D] of one subset; eps [K,B,D] the noise get_latent_samples draws
+    (likelihood.py:13-18: the posterior is repeated K times sample-major and reparameterised).  Decoders run in eval mode.
+    Returns {'PA','Lateral','text','joint'} scalars.  The reference flattens the K x B weights sample-major and then
+    views them as (batch_size, n_samples) (likelihood.py:140,217), i.e. row i of the log-mean-exp holds flat elements
+    i*K .. i*K+K-1; that grouping is reproduced here."""
+    mu, lv = subset_posterior
+    k, b = eps.shape[0], mu.shape[0]
+    mu_r = mu.unsqueeze(0).repeat(k, 1, 1).view(k * b, -1)
+    lv_r = lv.unsqueeze(0).repeat(k, 1, 1).view(k * b, -1)
+    z = (eps.view(k * b, -1) * torch.exp(0.5 * lv_r) + mu_r)
+    ctx = Ctx("eval")
+    rec = {"PA": decode_img(cfg, sd, "decoder_pa", z, ctx), "Lateral": decode_img(cfg, sd, "decoder_lat", z, ctx)}
+    logp_text = decode_text(cfg, sd, z, ctx)                                     # [K*B, L, V] log-probabilities
+    log_px = {}
+    for m in ("PA", "Lateral"):
+        tgt = batch[m].unsqueeze(0).repeat(k, 1, 1, 1, 1).view(k * b, *batch[m].shape[1:])
+        lp = -math.log(2 * scale) - torch.abs(tgt - rec[m]) / scale           # Laplace(loc, 0.75).log_prob
+        log_px[m] = lp.view(k * b, -1).sum(dim=1)
+    ids = batch["text"].long().unsqueeze(0).repeat(k, 1, 1).view(k * b, -1)
+    # OneHotCategorical(logits).log_prob(one_hot) = sum over the vocabulary of one_hot * normalised logits
+    norm_logits = logp_text - torch.logsumexp(logp_text, dim=-1, keepdim=True)
+    log_px["text"] = norm_logits.gather(-1, ids.unsqueeze(-1)).squeeze(-1).sum(dim=1)
+    log_q = gaussian_log_pdf(z, mu_r, lv_r)
+    log_pz = unit_gaussian_log_pdf(z)
+    out = {}
+    for m in ("PA", "Lateral", "text"):
+        w = (log_px[m] + log_pz - log_q).view(b, k)
+        out[m] = torch.mean(log_mean_exp(w, dim=1))
+    w = (log_px["PA"] + log_px["Lateral"] + log_px["text"] + log_pz - log_q).view(b, k)
+    out["joint"] = torch.mean(log_mean_exp(w, dim=1))
+    return out
+
+
 def leaf_state(sd, dtype=None):
     """Clone a state_dict into autograd leaves (float tensors) for gradient checks."""
     out = {}

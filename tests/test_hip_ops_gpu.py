@@ -332,3 +332,26 @@ def test_likelihoods_and_embedding():
         gout = torch.randn(*shape, d, generator=gen)
         check(f"embedding_bwd[{v}x{d}]", ops.embedding_bwd(ids.to(DEV), gout.to(DEV), v, 0),
               TB.embedding_bwd(ids, gout, v, 0), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("rows,tb,per_row", [(12, 4, 64 * 64), (6, 6, 4099), (10, 5, 7), (384, 64, 128 * 128)])
+def test_laplace_logprob_rows(rows, tb, per_row):
+    gen = torch.Generator().manual_seed(rows + per_row)
+    xh = torch.rand(rows, per_row, generator=gen)
+    x = torch.rand(tb, per_row, generator=gen)
+    ref = TB.laplace_logprob_rows(xh.double(), x.double(), 0.75)
+    got = ops.laplace_logprob_rows(xh.to(DEV), x.to(DEV), 0.75)
+    check("laplace_logprob_rows", got, ref, rtol=2e-6, atol_rel=2e-6)
+    # unaligned views take the scalar path
+    got = ops.laplace_logprob_rows(torch.cat([torch.zeros(1), xh.flatten()]).to(DEV)[1:].view(rows, per_row), x.to(DEV), 0.75)
+    check("laplace_logprob_rows/unaligned", got, ref, rtol=2e-6, atol_rel=2e-6)
+
+
+@pytest.mark.parametrize("rows,tb,L,V", [(12, 4, 128, 50), (6, 3, 300, 3517), (5, 5, 1, 9)])
+def test_token_logprob_rows(rows, tb, L, V):
+    gen = torch.Generator().manual_seed(rows + V)
+    logp = torch.log_softmax(torch.randn(rows, L, V, generator=gen), dim=-1)
+    ids = torch.randint(0, V, (tb, L), generator=gen).float()
+    ref = TB.token_logprob_rows(logp.double(), ids)
+    got = ops.token_logprob_rows(logp.to(DEV), ids.to(DEV))
+    check("token_logprob_rows", got, ref, rtol=2e-6, atol_rel=2e-6)

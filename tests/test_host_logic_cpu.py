@@ -146,3 +146,24 @@ def test_scalar_pack_and_train_loop(monkeypatch):
     assert all(np.isfinite(v) for v in out["last"].values())
     ev = RE.test(0, exp, loader, max_steps=1)
     assert np.isfinite(ev["total_loss"])
+
+
+def test_g4_likelihood_estimator_host(monkeypatch):
+    """mimic_amd.evaluation.eval_metrics.likelihood.calc_log_likelihood_batch (host logic on the torch emulation of the
+    ops) against the reference's values (tests/golden/g4_likelihood.npz)."""
+    torch_backend.install(monkeypatch)
+    from mimic_amd.evaluation.eval_metrics.likelihood import calc_log_likelihood_batch
+    g = load("g4_likelihood")
+    cfg = cfg_from(g["cfg"])
+    sd = R.init_state(cfg, seed=int(g["seed_weights"]))
+    batch, _ = R.synthetic_batch(cfg, cfg.batch_size, seed=int(g["seed_batch"]))
+    exp = build_exp(cfg, sd, "cpu", "eval")
+    with torch.no_grad():
+        lat = exp.mm_vae.inference(dict(batch))
+        for s_key in ("PA", "text", "Lateral_text", "Lateral_PA_text"):
+            ll = calc_log_likelihood_batch(exp, lat, s_key, exp.subsets[s_key], batch, num_imp_samples=int(g["K"]),
+                                           eps=torch.from_numpy(g[f"{s_key}/eps"]))
+            assert set(ll) == {"PA", "Lateral", "text", "joint"}
+            for m_key, v in ll.items():
+                ref = float(g[f"{s_key}/{m_key}"])
+                assert abs(v.item() - ref) <= 2e-5 * abs(ref) + 2e-4, (s_key, m_key, v.item(), ref)

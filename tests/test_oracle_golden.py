@@ -150,3 +150,24 @@ def test_g3_adam_trajectory():
           rtol=1e-4, atol=1e-6)
     close(sd["decoder_text.feature_generator.bias"], g["final/decoder_text.feature_generator.bias"],
           rtol=1e-4, atol=1e-6)
+
+
+def test_g4_likelihood_estimator():
+    """oracle restatement of calc_log_likelihood_batch / log_marginal_estimate / log_joint_estimate against the values
+    the reference computed with the same noise (tests/golden/g4_likelihood.npz, oracle/gen_golden.py:gen_g4)."""
+    g = load("g4_likelihood")
+    cfg = cfg_from(g["cfg"])
+    sd = R.init_state(cfg, seed=int(g["seed_weights"]))
+    batch, _ = R.synthetic_batch(cfg, cfg.batch_size, seed=int(g["seed_batch"]))
+    ctx = R.Ctx("eval")
+    with torch.no_grad():
+        enc = {"PA": R.encode_img(cfg, sd, "encoder_pa", batch["PA"], ctx),
+               "Lateral": R.encode_img(cfg, sd, "encoder_lat", batch["Lateral"], ctx),
+               "text": R.encode_text(cfg, sd, batch["text"], ctx)}
+        lat = R.fuse_latents(cfg, enc)
+        for s_key in ("PA", "text", "Lateral_text", "Lateral_PA_text"):
+            eps = torch.from_numpy(g[f"{s_key}/eps"])
+            ll = R.likelihood_estimates(cfg, sd, batch, lat["subsets"][s_key], eps)
+            for m_key in ("PA", "Lateral", "text", "joint"):
+                ref = float(g[f"{s_key}/{m_key}"])
+                assert abs(ll[m_key].item() - ref) <= 1e-5 * abs(ref) + 1e-4, (s_key, m_key, ll[m_key].item(), ref)

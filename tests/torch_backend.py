@@ -18,7 +18,7 @@ from mimic_amd.ops import Bn, Geom, Mask, RES_A, RES_B
 OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_reduce", "block_out_bwd",
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
-            "embedding_fwd", "embedding_bwd"]
+            "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows"]
 
 
 def install(monkeypatch):
@@ -282,6 +282,18 @@ def token_nll_bwd(ids, g, shape, norm):
     d = torch.zeros(shape, dtype=torch.float32, device=ids.device)
     d.reshape(-1, shape[-1]).scatter_(1, ids.reshape(-1, 1).long(), (-g / norm).expand(ids.numel(), 1))
     return d
+
+
+def laplace_logprob_rows(x_hat, target, scale):
+    rows, tb = x_hat.shape[0], target.shape[0]
+    tgt = target.reshape(tb, -1).repeat(rows // tb, 1)
+    return (-math.log(2 * scale) - (tgt - x_hat.reshape(rows, -1)).abs() / scale).sum(dim=1)
+
+
+def token_logprob_rows(logp, ids):
+    rows, tb = logp.shape[0], ids.shape[0]
+    idx = ids.long().repeat(rows // tb, 1)
+    return logp.gather(-1, idx.unsqueeze(-1)).squeeze(-1).sum(dim=1)
 
 
 def embedding_fwd(ids, table):
