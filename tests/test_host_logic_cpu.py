@@ -167,3 +167,37 @@ def test_g4_likelihood_estimator_host(monkeypatch):
             for m_key, v in ll.items():
                 ref = float(g[f"{s_key}/{m_key}"])
                 assert abs(v.item() - ref) <= 2e-5 * abs(ref) + 2e-4, (s_key, m_key, v.item(), ref)
+
+
+def test_input_pipeline_contract(monkeypatch):
+    """Mimic_testing sample contract (reference mimic/dataio/MimicDataset.py:414-431), loader glue, the
+    DistributedSampler sharding rule, and train() running from the loaders."""
+    from mimic_amd.dataio.MimicDataset import Mimic_testing
+    from mimic_amd.dataio.utils import DeviceSyntheticSource, PrefetchToDevice, get_data_loaders, shard_for_rank
+    torch_backend.install(monkeypatch)
+    cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=4)
+    exp = build_exp(cfg, R.init_state(cfg, seed=1), "cpu", "train")
+    exp.mm_vae.set_mask_replay(None)
+    exp.set_optimizer()
+    flags = exp.flags
+    ds = Mimic_testing(flags)
+    assert len(ds) == 2 * flags.batch_size
+    sample, label = ds[0]
+    assert set(sample) == {"PA", "Lateral", "text"} and tuple(sample["PA"].shape) == (1, 64, 64)
+    assert sample["PA"].dtype == torch.float32 and 0.0 <= float(sample["PA"].min()) and float(sample["PA"].max()) < 1.0
+    assert tuple(sample["text"].shape) == (flags.len_sequence,) and sample["text"].dtype == torch.float32
+    assert float(sample["text"].min()) >= 0 and float(sample["text"].max()) < flags.vocab_size
+    assert tuple(label.shape) == (3,) and set(label.tolist()) <= {0.0, 1.0}
+    flags.dataloader_workers = 0
+    sampler, loader = get_data_loaders(flags, ds, "train")
+    assert sampler is None and len(loader) == 2
+    out = RE.train(exp, PrefetchToDevice(loader, "cpu"))
+    assert out["steps"] == 2 and np.isfinite(out["last"]["total_loss"])
+    out = RE.train(exp, DeviceSyntheticSource(flags, "cpu", steps=3, seed=1))
+    assert out["steps"] == 3 and np.isfinite(out["last"]["total_loss"])
+    # DistributedSampler's split: every index once per epoch (plus wrap-around padding), disjoint across ranks
+    from torch.utils.data.distributed import DistributedSampler
+    for n, w in ((8, 2), (9, 4), (5, 3)):
+        for r in range(w):
+            ref = list(DistributedSampler(range(n), num_replicas=w, rank=r, shuffle=False))
+            assert shard_for_rank(n, r, w) == ref, (n, w, r)
