@@ -1,7 +1,7 @@
 """Debug aid (not a test): run one train step twice on the GPU -- HIP ops vs their torch emulation --
 recording every op call's outputs, and report where the two traces first diverge."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(REPO, "mopoe-mimic_amd"), os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
     sys.path.insert(0, p)
 import torch

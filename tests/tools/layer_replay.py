@@ -4,7 +4,7 @@ Records the arguments of each conv_fwd / conv_dgrad / conv_wgrad call of one tra
 distinct (op, geometry, fusion) REP times in a row between two events: unlike per-call events inside the
 step this is not inflated by event overhead on 20 us kernels."""
 import os, sys, collections
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
 os.environ["MOPOE_WGRAD_STREAM"] = "0"
 os.environ["MOPOE_NET_STREAMS"] = "0"

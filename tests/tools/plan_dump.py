@@ -1,6 +1,6 @@
 """Print the launch plans the autotuner picked for one config (tuning aid, not a test)."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
 import torch
 from mimic_amd import ops, run_epochs as RE

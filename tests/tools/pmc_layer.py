@@ -1,6 +1,6 @@
 """Launch one conv layer a few times under a forced plan (for rocprofv3 --pmc runs; not a test)."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
 import torch
 from mimic_amd import ops
