@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 6
+#define MOPOE_ABI_VERSION 7
 
 /* error codes */
 #define MOPOE_OK 0
@@ -148,11 +148,14 @@ int mopoe_block_out_bwd(const float* g, const float* s, float* dm, float* ds, in
 
 /* dx = mask * BatchNormBackward(dy; x) + add, with dy already ReLU-masked and sums = {sum dy,
  * sum dy*xhat} (both from mopoe_conv_dgrad's epilogue).  dgamma = sums[1], dbeta = sums[0].
- * colsum_dx (optional) += column sums of dx. */
+ * colsum_dx (optional) += column sums of dx.
+ * next_s / next_bn / next_sums (optional, all or none): dx is the gradient entering the PREVIOUS residual block, whose
+ * backward starts with mopoe_bn_bwd_reduce(dx, s_prev, bn_s_prev); passing that block's shortcut output and BatchNorm
+ * here accumulates next_sums (caller-zeroed double[2][C]) += {sum dx, sum dx*shat_prev} in the same pass. */
 int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows,
                        int32_t C, const mopoe_bn_ref* bn, const double* sums,
                        const mopoe_mask_ref* mask, float* dgamma, float* dbeta, float* colsum_dx,
-                       void* stream);
+                       const float* next_s, const mopoe_bn_ref* next_bn, double* next_sums, void* stream);
 
 /* running_mean/var momentum update for `n` BatchNorm layers in one launch (torch.nn.BatchNorm
  * train-mode side effect).  desc is a HOST array of n records {sums*, rmean*, rvar*, C, count} (device pointers

@@ -125,23 +125,30 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* 
 }
 
 // ---- dx = mask * BNbwd(dy; x) + add --------------------------------------------------------------------
-template <int VEC>
+// NEXT: dx is the gradient entering the previous residual block, whose first backward step is the pair of column
+// reductions {sum dx, sum dx * shat} over its shortcut output s (bn_bwd_reduce).  Producing them here saves that
+// kernel and its re-read of dx.
+template <int VEC, bool NEXT>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* dy, const float* x, const float* add,
                                                                 float* dx, long rows, int C, mopoe_bn_ref bn,
                                                                 const double* sums, mopoe_mask_ref mask, float* dgamma,
-                                                                float* dbeta, float* colsum_dx) {
+                                                                float* dbeta, float* colsum_dx, const float* next_s,
+                                                                mopoe_bn_ref next_bn, double* next_sums) {
+  constexpr int NACC = NEXT ? 3 : 1;
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
     const bool active = cv < L.Cv && L.tr < L.rpp;
-    float mean[VEC], rstd[VEC], gr[VEC], k1[VEC], k2[VEC], part[1][VEC];
+    float mean[VEC], rstd[VEC], gr[VEC], k1[VEC], k2[VEC], nmean[VEC], nrstd[VEC], part[NACC][VEC];
     for (int e = 0; e < VEC; ++e) {
-      mean[e] = rstd[e] = gr[e] = k1[e] = k2[e] = 0.f; part[0][e] = 0.f;
+      mean[e] = rstd[e] = gr[e] = k1[e] = k2[e] = nmean[e] = nrstd[e] = 0.f;
+      for (int k = 0; k < NACC; ++k) part[k][e] = 0.f;
       const int c = cv * VEC + e;
       if (active && c < C) {
         const BnC k = bn_coef(bn, c);
         mean[e] = k.mean; rstd[e] = k.rstd; gr[e] = k.scale;
         if (bn.mode == 1) { k1[e] = (float)(sums[c] * bn.inv_count); k2[e] = (float)(sums[C + c] * bn.inv_count); }
+        if (NEXT) { const BnC kn = bn_coef(next_bn, c); nmean[e] = kn.mean; nrstd[e] = kn.rstd; }
         if (blockIdx.x == 0 && L.tr == 0) {
           dgamma[c] = (float)sums[C + c];
           dbeta[c] = (float)sums[c];
@@ -152,8 +159,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
         const long off = r * C + (long)cv * VEC;
         const Vec<VEC> vd = Vec<VEC>::ld(dy + off), vx = Vec<VEC>::ld(x + off);
-        Vec<VEC> va, o;
+        Vec<VEC> va, vs, o;
         if (add) va = Vec<VEC>::ld(add + off);
+        if (NEXT) vs = Vec<VEC>::ld(next_s + off);
         const float* mrow = nullptr;
         if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
         else if (mask.kind == 2) mrow = mask.mask + r * C;
@@ -164,14 +172,21 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
           if (add) v += va.v[e];
           o.v[e] = v;
           part[0][e] += v;
+          if constexpr (NEXT) { part[1][e] += v; part[2][e] += v * ((vs.v[e] - nmean[e]) * nrstd[e]); }
         }
         o.st(dx + off);
       }
     }
-    if (colsum_dx) {
-      double* const od[1] = {nullptr};
-      float* const of[1] = {colsum_dx};
-      block_col_reduce<VEC, 1>(L, active, cbase, C, part, od, of);
+    if constexpr (NEXT) {
+      double* const od[3] = {nullptr, next_sums, next_sums + C};
+      float* const of[3] = {colsum_dx, nullptr, nullptr};
+      block_col_reduce<VEC, 3>(L, active, cbase, C, part, od, of);
+    } else {
+      if (colsum_dx) {
+        double* const od[1] = {nullptr};
+        float* const of[1] = {colsum_dx};
+        block_col_reduce<VEC, 1>(L, active, cbase, C, part, od, of);
+      }
     }
   }
 }
@@ -262,15 +277,22 @@ extern "C" int mopoe_block_out_bwd(const float* g, const float* s, float* dm, fl
 
 extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows, int32_t C,
                                   const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask, float* dgamma,
-                                  float* dbeta, float* colsum_dx, void* stream) {
+                                  float* dbeta, float* colsum_dx, const float* next_s, const mopoe_bn_ref* next_bn,
+                                  double* next_sums, void* stream) {
   EW_ARGCHECK(dy && x && dx && sums && dgamma && dbeta && bn && bn->mode != 0 && bn->C == C && rows > 0,
               "bn_bwd_apply: bad arguments");
+  const bool next = next_s != nullptr;
+  EW_ARGCHECK(!next || (next_bn && next_sums && next_bn->mode != 0 && next_bn->C == C),
+              "bn_bwd_apply: next_s needs next_bn (C channels) and next_sums");
   mopoe_mask_ref mk = mask ? *mask : mopoe_mask_ref{nullptr, 0, 1};
+  const mopoe_bn_ref nb = next ? *next_bn : mopoe_bn_ref{};
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(C, {dy, x, add, dx}))
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx);
+  const bool vec = vec_ok(C, {dy, x, add, dx, next_s});
+  const dim3 grid(ew_grid(rows, C, vec ? 4 : 1)), blk(EW_THREADS);
+#define MOPOE_APPLY(V_, N_) hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, N_>), grid, blk, 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx, next_s, nb, next_sums)
+  if (vec) { if (next) MOPOE_APPLY(4, true); else MOPOE_APPLY(4, false); }
+  else { if (next) MOPOE_APPLY(1, true); else MOPOE_APPLY(1, false); }
+#undef MOPOE_APPLY
   return check_launch("bn_bwd_apply");
 }
 

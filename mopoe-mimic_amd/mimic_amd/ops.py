@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -496,16 +496,20 @@ def block_out_bwd(g, s, bn_s: Bn, sums, mask: Optional[Mask], a=RES_A, b=RES_B, 
     return dm, ds, small[0], small[1], cdm, cds
 
 
-def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, want_colsum=False, small=None):
-    """-> dx, dgamma, dbeta, colsum_dx (or None); small: optional pre-zeroed float [3, C]."""
-    _dev(dy, x, sums, add)
+def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, want_colsum=False, small=None,
+                 next_s=None, next_bn: Optional[Bn] = None, next_sums=None):
+    """-> dx, dgamma, dbeta, colsum_dx (or None); small: optional pre-zeroed float [3, C].
+    next_s / next_bn / next_sums: also accumulate bn_bwd_reduce(dx, next_s, next_bn) into the pre-zeroed next_sums."""
+    _dev(dy, x, sums, add, next_s, next_sums)
     c = x.shape[-1]
     dx = torch.empty_like(x)
     if small is None:
         small = torch.zeros(3, c, dtype=torch.float32, device=x.device)
     cs = small[2] if want_colsum else None
+    nb = _bn(next_bn) if next_s is not None else None
     _check(lib().mopoe_bn_bwd_apply(_p(dy), _p(x), _p(add), _p(dx), C.c_int64(_rows(x)), c, _bn(bn), _p(sums),
-                                    _mask(mask), _p(small[0]), _p(small[1]), _p(cs), _stream()))
+                                    _mask(mask), _p(small[0]), _p(small[1]), _p(cs), _p(next_s), nb, _p(next_sums),
+                                    _stream()))
     return dx, small[0], small[1], cs
 
 

@@ -72,6 +72,7 @@ class MaskSource:
 # optimizer), so they are launched on a second HIP stream: on the deep / 1-D layers, whose grids cannot fill 256
 # CUs, the wgrad kernels then run concurrently with the dgrad / BatchNorm-backward chain instead of after it.
 WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
+FUSE_NEXT_REDUCE = os.environ.get("MOPOE_FUSE_NEXT_REDUCE", "1") != "0"
 LANES = os.environ.get("MOPOE_LANES", "0,1").split(",")   # 0 = weight gradients, 1 = projection-shortcut branch
 _side_streams = {}
 
@@ -227,13 +228,16 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
 
     lane = _WgradLane(g.device, 0)
     lane_s = _WgradLane(g.device, 1)
-    for spec, sv in zip(reversed(blocks), reversed(saved)):
+    order = list(zip(reversed(blocks), reversed(saved)))
+    sums_s = None   # {sum g, sum g*shat} of the block about to be processed, when the previous step already made them
+    for bi, (spec, sv) in enumerate(order):
         p, g1, g2 = spec.params, sv["g1"], sv["g2"]
         x, d1, s = sv["x"], sv["d1"], sv["s"]
         bn1, bn2, bns = sv["bn1"], sv["bn2"], sv["bns"]
         has_bias = p.conv1.bias is not None
         n = spec.name
-        sums_s = ops.bn_bwd_reduce(g, s, bns, sums=take_d(g2.Cout))
+        if sums_s is None:
+            sums_s = ops.bn_bwd_reduce(g, s, bns, sums=take_d(g2.Cout))
         dm, ds, dgs, dbs, cdm, cds = ops.block_out_bwd(g, s, bns, sums_s, sv["mask2"],
                                                        want_colsum_dm=has_bias, want_colsum_ds=True,
                                                        small=take_f(4, g2.Cout))
@@ -257,7 +261,16 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
             grads[f"{n}.conv2.bias"] = cdm
             grads[f"{n}.conv1.bias"] = cdc1
         lane_s.join()
-        g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin))
+        # the gradient leaving this block enters the previous one, whose backward starts with the two column
+        # reductions over its shortcut output: made in the same pass
+        nxt = order[bi + 1][1] if bi + 1 < len(order) else None
+        if nxt is not None and FUSE_NEXT_REDUCE:
+            sums_s = take_d(g1.Cin)
+            g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin),
+                                              next_s=nxt["s"], next_bn=nxt["bns"], next_sums=sums_s)
+        else:
+            sums_s = None
+            g, dg1, db1, _ = ops.bn_bwd_apply(dh1, x, bn1, sums1, add=dxs, small=take_f(3, g1.Cin))
         grads[f"{n}.bn1.weight"], grads[f"{n}.bn1.bias"] = dg1, db1
     lane.join()
     return g, fbuf

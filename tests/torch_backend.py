@@ -174,7 +174,8 @@ def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False
     return dm.contiguous(), ds.contiguous(), dgamma, dbeta, cdm, cds
 
 
-def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=None):
+def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=None, next_s=None, next_bn=None,
+                 next_sums=None):
     dx = _bn_bwd(dy, x, bn, sums)
     mm = _mask_mult(dx, mask)
     if mm is not None:
@@ -182,7 +183,10 @@ def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=
     if add is not None:
         dx = dx + add
     cs = dx.reshape(-1, dx.shape[-1]).sum(0) if want_colsum else None
-    return dx.contiguous(), sums[1].float(), sums[0].float(), cs
+    dx = dx.contiguous()
+    if next_s is not None:
+        next_sums += bn_bwd_reduce(dx, next_s, next_bn)
+    return dx, sums[1].float(), sums[0].float(), cs
 
 
 def bn_running_update(entries, momentum=0.1):
