@@ -101,8 +101,10 @@ def main():
     dev_index = local_rank if local_rank < ndev else local_rank % ndev   # (rehearsal: several ranks on one GPU)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    force_dp = os.environ.get("MOPOE_FORCE_DP", "0") == "1"   # rehearsal: the data-parallel code path with one rank
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("MOPOE_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; gloo only for rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -128,7 +130,7 @@ def main():
     # (never captured) between them.  MOPOE_GRAPH=0 selects the eager step (RCCL overlapped with backward).
     use_graph = os.environ.get("MOPOE_GRAPH", "1") != "0"
     exp.set_optimizer(capturable=use_graph)
-    reducer = GradAllReducer(exp.mm_vae, world) if world > 1 else None
+    reducer = GradAllReducer(exp.mm_vae, world, force=force_dp) if (world > 1 or force_dp) else None
     if reducer is not None:
         reducer.broadcast_parameters()
     batches = synthetic_batches(flags, 4, device, seed=1 + rank)
@@ -146,7 +148,7 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
             graphed, use_graph = None, False
             exp.set_optimizer(capturable=False)
-    if world > 1:   # every rank must take the same path (graphed ranks issue their collectives at different points)
+    if world > 1 or force_dp:   # every rank must take the same path (graphed ranks issue their collectives at different points)
         ok = torch.tensor([1.0 if graphed is not None else 0.0], device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if use_graph and ok.item() < 0.5:
@@ -171,7 +173,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -194,7 +196,7 @@ def main():
     host_ms = (host_done[0] - t0) / args.steps * 1e3
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,7 +264,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

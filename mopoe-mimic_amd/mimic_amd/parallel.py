@@ -29,12 +29,14 @@ NET_NAMES = ("encoder_pa", "encoder_lat", "encoder_text", "decoder_pa", "decoder
 
 
 class GradAllReducer:
-    def __init__(self, module: torch.nn.Module, world_size: int):
+    def __init__(self, module: torch.nn.Module, world_size: int, force: bool = False):
+        """force: run the collectives even with a single rank (rehearsal of the RCCL path on a 1-GPU box)"""
         self.module, self.world_size = module, world_size
+        self.active = world_size > 1 or (force and dist.is_initialized())
         self._pending = []       # (work handle, arena)
         self._avg = None
         self._deferred = None    # list of arenas while a step is being captured into a hipGraph (no collectives inside)
-        if world_size > 1:
+        if self.active:
             backend = dist.get_backend()
             self._avg = dist.ReduceOp.AVG if backend == "nccl" else None   # gloo has no AVG: SUM then scale
             for name in NET_NAMES:
@@ -49,14 +51,14 @@ class GradAllReducer:
                 net._grad_reducer = None
 
     def broadcast_parameters(self, src: int = 0):
-        if self.world_size <= 1:
+        if not self.active:
             return
         with torch.no_grad():
             for t in list(self.module.parameters()) + list(self.module.buffers()):
                 dist.broadcast(t, src)
 
     def sync_buffers(self, src: int = 0):
-        if self.world_size <= 1:
+        if not self.active:
             return
         for b in self.module.buffers():
             dist.broadcast(b, src)
@@ -69,7 +71,7 @@ class GradAllReducer:
         """Called from a network's backward node: ``arena`` holds (as views) the trunk gradients.  Autograd
         adopts those views as ``param.grad`` (no copy) when the gradients were cleared with
         ``zero_grad(set_to_none=True)``, so reducing the arena in place reduces ``param.grad``."""
-        if self.world_size <= 1:
+        if not self.active:
             return
         if self._deferred is not None:
             self._deferred.append(arena)
@@ -85,30 +87,25 @@ class GradAllReducer:
         arenas, self._deferred = self._deferred, None
         return arenas
 
-    def reduce_static(self, arenas, outside, flat):
-        """all-reduce the recorded arenas in place and, through the preallocated staging buffer `flat`, the
-        gradients `outside` them"""
+    def reduce_static(self, arenas, flat):
+        """all-reduce (average) the recorded arenas and the staging buffer `flat` in place.  The gather of the
+        gradients outside the arenas into `flat` and the scatter back are part of the captured graphs."""
         works = [self._launch(a) for a in arenas]
-        if outside:
-            torch.cat([g.reshape(-1) for g in outside], out=flat)
+        if flat is not None:
             works.append(self._launch(flat))
         for w in works:
             w.wait()
         if self._avg is None:
             for a in arenas:
                 a.div_(self.world_size)
-            if outside:
+            if flat is not None:
                 flat.div_(self.world_size)
-        off = 0
-        for g in outside:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
 
     def all_reduce_grads(self):
         """Wait for the per-network collectives started during backward and finish averaging; then reduce, in
         one flat staging bucket, every gradient that does not live in a reduced arena (stems, heads, latent
         projections, embedding -- about 3 % of the bytes -- or everything, if autograd had to copy)."""
-        if self.world_size <= 1:
+        if not self.active:
             return
         ranges = []
         for work, t in self._pending:

@@ -85,7 +85,7 @@ class ScalarPack:
             names += [f"latents/{k}/mu", f"latents/{k}/logvar"]
             vals += [mu.detach().mean().reshape(1), lv.detach().mean().reshape(1)]
         packed = torch.cat(vals)
-        if reducer is not None and reducer.world_size > 1:
+        if reducer is not None and reducer.active:
             packed = reducer.mean_scalars(packed)
         if self.host is None or self.host.numel() != packed.numel():
             self.host = torch.empty(packed.numel(), dtype=torch.float32,
@@ -144,7 +144,7 @@ class GraphedTrainStep:
                  reducer: typing.Optional["GradAllReducer"] = None, warmup: int = 2):
         from .layout import BnParams
         self.exp, self.pack = exp, pack
-        self.reducer = reducer if (reducer is not None and reducer.world_size > 1) else None
+        self.reducer = reducer if (reducer is not None and reducer.active) else None
         dev = exp.flags.device
         self.static = {k: v.to(dev).clone() for k, v in example_batch[0].items()}
         self.stream = torch.cuda.Stream(device=dev)
@@ -165,21 +165,30 @@ class GraphedTrainStep:
             # other threads keep making HIP calls here (the process group's watchdog polls events): they must not
             # invalidate the capture, hence thread_local
             self.reducer.begin_deferred()
+            self.arenas, self.outside, self.flat = [], [], None
             try:
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.routine = basic_routine_epoch(exp, (dict(self.static), None))
                     exp.optimizer.zero_grad(set_to_none=True)
                     self.routine["total_loss"].backward()
+                    # gradients that do not live in a network arena (stems, heads, latent projections, embedding):
+                    # gathered into one staging buffer here, scattered back at the head of the optimiser graph
+                    self.arenas = self.reducer.end_deferred()
+                    ranges = [(a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()) for a in self.arenas]
+                    self.outside = [p.grad for p in exp.mm_vae.parameters()
+                                    if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]
+                    if self.outside:
+                        self.flat = torch.cat([g.reshape(-1) for g in self.outside])
             finally:
-                self.arenas = self.reducer.end_deferred()
-            ranges = [(a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()) for a in self.arenas]
-            self.outside = [p.grad for p in exp.mm_vae.parameters()
-                            if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]
-            n_out = sum(g.numel() for g in self.outside)
-            self.flat = torch.empty(n_out, dtype=torch.float32, device=dev) if n_out else None
+                if self.reducer._deferred is not None:
+                    self.reducer.end_deferred()
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, stream=self.stream, pool=self.graph.pool(),
                                   capture_error_mode="thread_local"):
+                off = 0
+                for g in self.outside:
+                    g.copy_(self.flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
                 exp.optimizer.step()
         # (a capture only records: parameters, optimiser state and running statistics are untouched by it)
         self._bn_bump = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
@@ -191,7 +200,7 @@ class GraphedTrainStep:
             self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         if self.reducer is not None:
-            self.reducer.reduce_static(self.arenas, self.outside, self.flat)
+            self.reducer.reduce_static(self.arenas, self.flat)
             self.graph_opt.replay()
             if self.pack is not None:
                 self.pack.submit(self.routine, self.reducer)
