@@ -8,6 +8,9 @@
 One "step" = run_epochs.train's loop body (reference mimic/run_epochs.py:122-142) on one synthetic batch
 already resident in HBM: forward (3 encoders, fused latent kernel, 3 decoders, likelihoods), loss,
 backward, gradient all-reduce (N > 1), Adam, and the asynchronous read-back of the 18 logged scalars.
+The step is captured once into hipGraphs (run_epochs.GraphedTrainStep) and replayed; the set-up before
+the W warm-up steps runs two eager steps (launch plans are tuned there) and the capture.  MOPOE_GRAPH=0
+times the eager step instead.
 Workload at N = 1: BASELINE config #2 = 3 modalities (PA + Lateral + text), 128x128, class_dim 128,
 DIM_img 64, DIM_text 128, vocab 3517, batch 64 per GPU, fp32, train mode (BatchNorm batch statistics,
 dropout on).  Weak scaling: 64 samples per GPU.
@@ -16,7 +19,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      the dominant kernel (fp32-MFMA implicit-GEMM) timed with HIP events on its launch stream
                 in a second pass of the same steps (so the events do not perturb `value`)
   cpu_baseline  the CPU oracle (oracle/mopoe_ref.py, a port) timed on this host's cores on a bounded
-                sample (1 warm-up + 2 steps of the same workload).
+                sample (1 warm-up + 1 timed step of the same workload, ~35 s of CPU work).
 """
 import argparse
 import json
@@ -53,7 +56,7 @@ def synthetic_batches(flags, n, device, seed):
     return out
 
 
-def cpu_baseline(cfg_name, steps=2):
+def cpu_baseline(cfg_name, steps=1):
     """CPU restatement (oracle) of the same train step on this host: fwd + autograd bwd + Adam."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import mopoe_ref as R
