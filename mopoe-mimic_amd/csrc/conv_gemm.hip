@@ -10,11 +10,18 @@
 //               real input pixel are multiplied.  convT forward, conv input-gradient.
 //   wgrad_gemm   : dWp[tap][Cin][Cout] = sum_pixels T(x)[..][Cin]^T * dy[..][Cout]
 //
-// Block = 256 threads = 4 waves in a 2x2 arrangement; a wave owns a (BM/2)x(BN/2) sub-tile made of
-// 32x32 MFMA tiles; K is consumed in chunks of 16 through double-buffered LDS tiles stored K-major
-// ([k][m], [k][n]) so that every MFMA operand read is a conflict-free ds_read_b32 of consecutive
-// lanes.  BatchNorm+ReLU of the operand, bias, dropout mask, BN statistics and the ReLU/BN backward
-// reductions are fused into the operand load / epilogue (see include/mopoe_hip.h).
+// Blocks are 4 or 8 waves; a wave owns a (BM/WGM)x(BN/WGN) sub-tile made of 32x32 MFMA tiles; K is consumed in
+// chunks of 16 (or 32) through double-buffered LDS tiles stored K-major ([k][m], [k][n]) so that every MFMA operand
+// read is a conflict-free ds_read of consecutive lanes.  BatchNorm+ReLU of the operand, bias, dropout mask, BN
+// statistics and the ReLU/BN backward reductions are fused into the operand load / epilogue (include/mopoe_hip.h).
+//
+// What shapes the main loops (measured): VALU work does not hide beside fp32 MFMAs on this
+// chip, so the loops carry as few vector instructions per MFMA as possible -- the K advance of every operand is a
+// scalar add in the buffer load's soffset, per-thread byte offsets change only with the tap (gather) or never
+// (weights, wgrad's pixel slots), out-of-range rows read zeros through the hardware range check (voffset 2^31),
+// LDS addresses are base + immediate (loop unrolled by two), and the mode flags are template specialisations.
+// The tile and the split of the reduction are launch-plan arguments (mopoe_conv_plan): the host mirror measures
+// the candidates per layer; the heuristics in launch_gather / mopoe_conv_wgrad are only the fallback.
 #include <stdlib.h>
 #include <algorithm>
 #include <initializer_list>
