@@ -79,7 +79,7 @@ def cpu_baseline(cfg_name, steps=1):
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
     return {"value": bsz / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps (after 1 warm-up) of the same workload (B={bsz}) through oracle/mopoe_ref.py: "
+            "sample": f"{steps} step(s) (after 1 warm-up) of the same workload (B={bsz}) through oracle/mopoe_ref.py: "
                       f"fwd + autograd bwd + Adam, {t:.2f} s/step"}
 
 
