@@ -98,6 +98,8 @@ size_t mopoe_conv_workspace_bytes(void);
  *   fwd / dgrad: tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 output tile
  *                      (0, 1, 3: 8 waves per block; 2, 4: 4 waves) | 5, 6 = tiles 2, 4 with a 32-deep K chunk
  *                      | 7 = 128x128 with 4 waves per block
+ *                      | 8..11 = 128x128, 256x64, 64x64, 128x64 tiles of the LDS-free kernel (operands streamed from
+ *                        global memory into the MFMA registers; needs channel counts that are multiples of 8)
  *                split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction (needs workspace)
  *   wgrad:       tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap)
  *                split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp) */
@@ -252,8 +254,9 @@ int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int6
  *          1 forward, 2 forward with BN+ReLU on the operand, 3 input gradient)
  *   32..34 gather_gemm_kernel, scalar path: 128x128, 256x64, 64x64
  *   36..41 wgrad_gemm_kernel, vector path: (128x128 ? 0 : 3) + spec (0 run-time modes, 1 plain, 2 BN+ReLU on x)
- *   42..43 wgrad_gemm_kernel, scalar path: 128x128, 64x64 */
-#define MOPOE_PROF_KINDS 44
+ *   42..43 wgrad_gemm_kernel, scalar path: 128x128, 64x64
+ *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec */
+#define MOPOE_PROF_KINDS 60
 int mopoe_prof_enable(int32_t on);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

@@ -63,7 +63,8 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 //   gather, scalar path:  32 + {0: 128x128, 1: 256x64, 2: 64x64}                   kinds 32..34
 //   wgrad,  vector path:  36 + (128x128 ? 0 : 3) + spec   (spec 0..2)              kinds 36..41
 //   wgrad,  scalar path:  42 + (128x128 ? 0 : 1)                                   kinds 42..43
-enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_NKINDS = MOPOE_PROF_KINDS };
+//   direct (LDS-free) gather: 44 + (tile - 8) * 4 + spec                           kinds 44..59
+enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {
   hipStream_t stream;
   int slot;

@@ -461,99 +461,217 @@ void gather_gemm_kernel(const GemmArgs a) {
     }
     if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
-    // ---- epilogue of this M tile ------------------------------------------------------------------------
-    const float* __restrict__ xin = a.xin;
-    float* __restrict__ Yp = a.Y;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        // four consecutive rows per group: issue their independent loads first, then the dependent math
-        long yrows[4];
-        const float* mrows[4];
-        float xv[4][TJ];
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const long m = m0 + wm * WM + i * 32 + r4 + 8 * rg + 4 * lhi;
-          yrows[r4] = -1;
-          mrows[r4] = nullptr;
-          if (m < a.rows_per_phase) {
-            // 32-bit index arithmetic (64-bit integer division costs hundreds of cycles per element)
-            const unsigned mu = (unsigned)m;
-            const unsigned nn = mu / (unsigned)hw;
-            if (a.form == 0) {
-              yrows[r4] = m;
-            } else {
-              const unsigned rem = mu - nn * (unsigned)hw;
-              const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
-              yrows[r4] = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
-            }
-            if (a.mask.kind == 1) mrows[r4] = a.mask.mask + (long)nn * a.Cn;
-            else if (a.mask.kind == 2) mrows[r4] = a.mask.mask + yrows[r4] * a.Cn;
-          }
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            xv[r4][j] = 0.f;
-            if (do_relu_bn && !a.partial && yrows[r4] >= 0 && n < a.Cn) xv[r4][j] = xin[yrows[r4] * a.Cn + n];
-          }
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const long yrow = yrows[r4];
-          if (yrow < 0) continue;
-          const int r = rg * 4 + r4;
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            const int n = n0 + wn * WN + j * 32 + l31;
-            if (n >= a.Cn) continue;
-            if (a.partial) {  // split-K: raw partial sums, reduced by splitk_epilogue_kernel
-              a.partial[((long)split * a.rows_total + yrow) * a.Cn + n] = acc[i][j][r];
-              continue;
-            }
-            float v = acc[i][j][r] + cbias[j];
-            if (mrows[r4]) v *= mrows[r4][n];
-            if (do_relu_bn) {
-              const float xi = xv[r4][j];
-              v = (fmaf(xi, rbc[j].scale, rbc[j].shift) > 0.f) ? v : 0.f;
-              s1[j] += v;
-              s2[j] += v * ((xi - rbc[j].mean) * rbc[j].rstd);
-            } else {
-              s1[j] += v;
-              s2[j] += v * v;
-            }
-            Yp[yrow * a.Cn + n] = v;
-          }
-        }
-      }
-    }
+#include "gemm_epilogue.inc"
   }
 
-  // ---- column statistics: one atomic per column per block ------------------------------------------------
-  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
-  if (sums && !a.partial) {
-    __shared__ float cs[2][WGM * WGN][64];  // [stat][wave][column within the wave tile (<= 64)]
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      // lanes l and l+32 hold the same column
-      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (lhi == 0) { cs[0][wave][j * 32 + l31] = t1; cs[1][wave][j * 32 + l31] = t2; }
+#include "gemm_colstats.inc"
+}
+
+// =====================================================================================================
+// direct_gemm: the same implicit GEMM with both operands streamed from global memory straight into the MFMA
+// registers -- no LDS tiles, no barriers in the K loop, (almost) no vector instructions beside the MFMAs.
+//
+// v_mfma_f32_32x32x2_f32 takes, per lane, A[row = lane % 32][k = lane / 32] and B[k = lane / 32][col = lane % 32]:
+// which two K indices one instruction multiplies is free as long as A and B agree.  A lane of the upper half
+// (lhi = 1) therefore owns K offsets +4..+7 of an 8-deep step and the lower half +0..+3: every lane loads ONE
+// 16-byte run of its own row (rows are K-contiguous in the channels-last layout) and the four components feed four
+// MFMAs.  Weights: K-contiguous for the input gradient (same 16-byte trick), N-contiguous for the forward (one
+// 4-byte load per MFMA, 32 consecutive columns per half-wave).  The K advance is the loads' scalar offset; the
+// per-lane byte offsets change only with the tap.  Reuse between the waves of a block (same rows / same columns)
+// is served by the CU's vector L1.
+// SPEC: 1 forward, plain operand   2 forward, BN+ReLU on the operand   3 input gradient.  Needs Ck % 8 == 0.
+// =====================================================================================================
+__device__ __forceinline__ float bld1s(__amdgpu_buffer_rsrc_t srd, unsigned byte_off, unsigned s_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, byte_off, s_off, 0));
+}
+
+template <int WGM, int WGN, int TI, int TJ, int SPEC>
+__global__ __launch_bounds__(64 * WGM * WGN, (TI * TJ >= 4 ? 3 : 4)) void direct_gemm_kernel(const GemmArgs a) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = TI * 32, WN = TJ * 32, BM = WGM * WM, BN = WGN * WN;
+  constexpr bool xform = SPEC == 2;
+  constexpr int w_nk = SPEC == 3 ? 1 : 0;
+  constexpr int KS = 8;                          // K floats per step (4 per half-wave)
+
+  __shared__ __attribute__((aligned(16))) float bnS[xform ? MAX_BN_C : 4];
+  __shared__ __attribute__((aligned(16))) float bnT[xform ? MAX_BN_C : 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int n0 = blockIdx.y * BN;
+  const int phase = blockIdx.z / a.nsplit;
+  const int split = blockIdx.z - phase * a.nsplit;
+
+  int nty, ntx, ky0, kx0, kstep_y, kstep_x, dsgn, cy = 0, cx = 0, phy = 0, phx = 0;
+  if (a.form == 0) {
+    nty = a.kh; ntx = a.kw; ky0 = 0; kx0 = 0; kstep_y = 1; kstep_x = 1; dsgn = 1;
+  } else {
+    phy = phase / a.sw; phx = phase % a.sw;
+    const int ry = (phy + a.ph) % a.sh, rx = (phx + a.pw) % a.sw;
+    nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
+    ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
+    ky0 = ry; kx0 = rx; kstep_y = a.sh; kstep_x = a.sw; dsgn = -1;
+    cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
+  }
+  const int nkc = a.Ck / KS;                     // Ck % 8 == 0 (host)
+  const int total_all = nty * ntx * nkc;
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)a.w_bytes, 0x00020000);
+  const int per_split = (total_all + a.nsplit - 1) / a.nsplit;
+  const int it_beg = split * per_split;
+  const int it_end = it_beg + per_split < total_all ? it_beg + per_split : total_all;
+  const int total = it_end > it_beg ? it_end - it_beg : 0;
+
+  if (xform) {
+    for (int c = tid; c < ((a.Ck + 3) & ~3); c += NT) {
+      BnC k = BnC{0.f, 0.f, 0.f, 0.f};
+      if (c < a.Ck) k = bn_coef(a.bn_in, c);
+      bnS[c] = k.scale;
+      bnT[c] = k.shift;
     }
     __syncthreads();
-    // waves with the same wn own the same columns: combine them, then one atomic per column
-    for (int c = tid; c < BN; c += NT) {
-      const int wnc = c / WN, cc = c - wnc * WN;
-      const int n = n0 + c;
-      if (n < a.Cn) {
-        float t1 = 0.f, t2 = 0.f;
+  }
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const int hw = a.Hq * a.Wq;
+
+  float cbias[TJ], s1[TJ], s2[TJ];
+  BnC rbc[TJ];
+  unsigned voffB[TJ];
 #pragma unroll
-        for (int w = 0; w < WGM; ++w) { t1 += cs[0][w * WGN + wnc][cc]; t2 += cs[1][w * WGN + wnc][cc]; }
-        atomic_add_f64(sums + n, (double)t1);
-        atomic_add_f64(sums + a.Cn + n, (double)t2);
+  for (int j = 0; j < TJ; ++j) {
+    const int n = n0 + wn * WN + j * 32 + l31;
+    s1[j] = s2[j] = 0.f;
+    cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
+    rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
+    if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+    if (n < a.Cn) voffB[j] = w_nk ? ((unsigned)n * (unsigned)a.Cout_w + (unsigned)lhi * 4u) * 4u
+                                  : ((unsigned)lhi * 4u * (unsigned)a.Cout_w + (unsigned)n) * 4u;
+    else voffB[j] = OOB;
+  }
+
+  const long nMt = (a.rows_per_phase + BM - 1) / BM;
+  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+    const long m0 = mt * BM;
+    int ry0[TI], rx0[TI], rbase[TI];
+    bool rvalid[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const long m = m0 + wm * WM + i * 32 + l31;
+      rvalid[i] = m < a.rows_per_phase;
+      const unsigned mm = rvalid[i] ? (unsigned)m : 0u;
+      const int n = (int)(mm / (unsigned)hw);
+      const int rem = (int)(mm - (unsigned)n * (unsigned)hw);
+      const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
+      if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
+      else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
+      rbase[i] = (n * a.Hx + ry0[i]) * a.Wx + rx0[i];
+    }
+
+    int ld_tap = it_beg / nkc;
+    int ld_kc = (it_beg - ld_tap * nkc) * KS;
+    bool tap_dirty = true;
+    unsigned offA[TI], offW = 0;
+    bool okA[TI];
+    // two register sets: step s+1 is in flight while step s is multiplied
+    float4 ra[2][TI], rsc[2], rsh[2];
+    float rbd[2][TJ][4];
+    float4 rb4[2][TJ];
+    bool rok[2][TI];
+
+    auto load_step = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      if (tap_dirty) {
+        const int jy = ld_tap / ntx, jx = ld_tap - jy * ntx;
+        const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+        const int tapoff = dsgn * (jy * a.Wx + jx);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
+          okA[i] = rvalid[i] & ((unsigned)iy < (unsigned)a.Hx) & ((unsigned)ix < (unsigned)a.Wx);
+          offA[i] = okA[i] ? (unsigned)(rbase[i] + tapoff) * (unsigned)a.Ck * 4u + (unsigned)lhi * 16u : OOB;
+        }
+        offW = (unsigned)wtap * (unsigned)a.Cin_w * (unsigned)a.Cout_w * 4u;
+        tap_dirty = false;
+      }
+      const unsigned sA = (unsigned)ld_kc * 4u;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) { ra[buf][i] = bld4s(srdX, offA[i], sA); rok[buf][i] = okA[i]; }
+      if (w_nk) {
+        const unsigned sB = offW + (unsigned)ld_kc * 4u;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) rb4[buf][j] = bld4s(srdW, voffB[j], sB);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned sB = offW + (unsigned)(ld_kc + e) * (unsigned)a.Cout_w * 4u;
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) rbd[buf][j][e] = bld1s(srdW, voffB[j], sB);
+        }
+      }
+      if (xform) {
+        rsc[buf] = *reinterpret_cast<const float4*>(&bnS[ld_kc + lhi * 4]);
+        rsh[buf] = *reinterpret_cast<const float4*>(&bnT[ld_kc + lhi * 4]);
+      }
+      ld_kc += KS;
+      if (ld_kc >= a.Ck) { ld_kc = 0; ++ld_tap; tap_dirty = true; }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mma_step = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      float av[TI][4];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        float4 v = ra[buf][i];
+        if (xform) {   // spatial padding must stay zero AFTER the transform
+          const bool ok = rok[buf][i];
+          v.x = ok ? fmaxf(fmaf(v.x, rsc[buf].x, rsh[buf].x), 0.f) : 0.f;
+          v.y = ok ? fmaxf(fmaf(v.y, rsc[buf].y, rsh[buf].y), 0.f) : 0.f;
+          v.z = ok ? fmaxf(fmaf(v.z, rsc[buf].z, rsh[buf].z), 0.f) : 0.f;
+          v.w = ok ? fmaxf(fmaf(v.w, rsc[buf].w, rsh[buf].w), 0.f) : 0.f;
+        }
+        av[i][0] = v.x; av[i][1] = v.y; av[i][2] = v.z; av[i][3] = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          float bv;
+          if (w_nk) bv = e == 0 ? rb4[buf][j].x : (e == 1 ? rb4[buf][j].y : (e == 2 ? rb4[buf][j].z : rb4[buf][j].w));
+          else bv = rbd[buf][j][e];
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv, acc[i][j], 0, 0, 0);
+        }
+      }
+    };
+
+    if (total > 0) load_step(std::integral_constant<int, 0>{});
+    for (int it = 0; it < total; it += 2) {
+      if (it + 1 < total) load_step(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(std::integral_constant<int, 0>{});
+      if (it + 1 < total) {
+        if (it + 2 < total) load_step(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(std::integral_constant<int, 1>{});
       }
     }
+
+#include "gemm_epilogue.inc"
   }
+
+#include "gemm_colstats.inc"
 }
 
 // =====================================================================================================
@@ -970,17 +1088,19 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 7) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..7)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 11) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..11)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
     if ((cfg == 5 || cfg == 6) && Ck % 32 != 0) cfg -= 3;   // 5, 6 = tiles 2, 4 with a 32-deep K chunk
+    if (cfg >= 8 && (!vec || Ck % 8 != 0)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels
   }
-  static const int TILE_BM[8] = {128, 256, 64, 256, 128, 64, 128, 128}, TILE_BN[8] = {128, 64, 64, 128, 64, 64, 64, 128};
+  static const int TILE_BM[12] = {128, 256, 64, 256, 128, 64, 128, 128, 128, 256, 64, 128};
+  static const int TILE_BN[12] = {128, 64, 64, 128, 64, 64, 64, 128, 128, 64, 64, 64};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
-  const int gbk = (cfg == 5 || cfg == 6) ? 32 : 16;
+  const int gbk = (cfg == 5 || cfg == 6) ? 32 : (cfg >= 8 ? 8 : 16);
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
@@ -998,14 +1118,15 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
-  const long persist = (cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS;   // 4-wave blocks: 3 per CU
+  const long persist = cfg >= 8 ? 4096 : ((cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS);   // 4-wave blocks: 3 per CU
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
     const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
-    ProfScope prof(stream, flops, vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg);
+    ProfScope prof(stream, flops, cfg >= 8 ? PROF_DIRECT + (cfg - 8) * 4 + spec
+                                           : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg));
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
     // specialised main loops (spec != 0): vector path with Ck a multiple of the K chunk (every layer of the four
     // networks except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
@@ -1016,7 +1137,17 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     else if (spec == 3) hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, BK_, true, 3>), grid, dim3(THREADS_), 0, stream, a); \
     else hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, WM_, WN_, 16, true, 0>), grid, dim3(THREADS_), 0, stream, a);                \
   } while (0)
-    if (vec) {
+#define MOPOE_LAUNCH_DIRECT(WM_, WN_, TI_, TJ_)                                                                                   \
+  do {                                                                                                                          \
+    if (spec == 1) hipLaunchKernelGGL((direct_gemm_kernel<WM_, WN_, TI_, TJ_, 1>), grid, dim3(64 * WM_ * WN_), 0, stream, a);      \
+    else if (spec == 2) hipLaunchKernelGGL((direct_gemm_kernel<WM_, WN_, TI_, TJ_, 2>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
+    else hipLaunchKernelGGL((direct_gemm_kernel<WM_, WN_, TI_, TJ_, 3>), grid, dim3(64 * WM_ * WN_), 0, stream, a);                \
+  } while (0)
+    if (cfg == 8) MOPOE_LAUNCH_DIRECT(2, 2, 2, 2);
+    else if (cfg == 9) MOPOE_LAUNCH_DIRECT(4, 1, 2, 2);
+    else if (cfg == 10) MOPOE_LAUNCH_DIRECT(2, 2, 1, 1);
+    else if (cfg == 11) MOPOE_LAUNCH_DIRECT(2, 1, 2, 2);
+    else if (vec) {
       if (cfg == 0) MOPOE_LAUNCH_TILE(128, 128, 2, 4, 16, 512);
       else if (cfg == 1) MOPOE_LAUNCH_TILE(256, 64, 4, 2, 16, 512);
       else if (cfg == 3) MOPOE_LAUNCH_TILE(256, 128, 4, 2, 16, 512);
@@ -1031,6 +1162,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
       else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, 2, 2, 16, false>), grid, dim3(256), 0, stream, a);
     }
 #undef MOPOE_LAUNCH_TILE
+#undef MOPOE_LAUNCH_DIRECT
     if (int rc = check_launch("gather_gemm")) return rc;
     if (a.partial) {
       dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), EPI_MAX_BLOCKS_Y));

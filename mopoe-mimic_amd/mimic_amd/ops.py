@@ -238,9 +238,13 @@ _TUNE_REPS = 3
 # so that one warm-up step settles every plan.
 TUNE_AFTER_CALLS = int(os.environ.get("MOPOE_TUNE_AFTER_CALLS", "0"))
 TUNE_ALPHA = float(os.environ.get("MOPOE_TUNE_ALPHA", "1.0"))
+# tiles 8..11 (LDS-free kernel) among the tuner's candidates: off by default -- they win on many small layers when timed
+# alone but the step as a whole (three modalities' kernels running side by side) is not faster with them
+DIRECT_TILES = os.environ.get("MOPOE_DIRECT_TILES", "0") != "0"
 _conv_calls = 0
 _plans = {}
-_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128))
+_GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128),
+                 (128, 128), (256, 64), (64, 64), (128, 64))   # 8..11: the LDS-free kernel
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
 
 
@@ -310,6 +314,8 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
             continue   # vector-path-only tiles
         if tile in (5, 6) and ck % 32:
             continue   # 32-deep K chunk
+        if tile >= 8 and (ck % 8 or not DIRECT_TILES):
+            continue   # LDS-free kernel: 8-deep K steps
         cap = 512 if tile in (0, 1, 3) else 768          # blocks resident at once (8-wave / 4-wave tiles)
         cands[(tile, 1)] = min(1.0, blocks / cap)
         for s in _SPLITS:
@@ -691,7 +697,7 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 44
+    names = [None] * 60
     for tile, tt in enumerate(_TILE_TEMPLATES):
         for spec in range(4):
             names[tile * 4 + spec] = f"gather_gemm_kernel<{tt}, true, {spec}>"
@@ -701,6 +707,9 @@ def _prof_kind_names():
         for spec in range(3):
             names[36 + 3 * i + spec] = f"wgrad_gemm_kernel<{tt}, true, {spec}>"
         names[42 + i] = f"wgrad_gemm_kernel<{tt}, false, 0>"
+    for i, tt in enumerate(("2, 2, 2, 2", "4, 1, 2, 2", "2, 2, 1, 1", "2, 1, 2, 2")):
+        for spec in range(1, 4):
+            names[44 + 4 * i + spec] = f"direct_gemm_kernel<{tt}, {spec}>"
     return names
 
 

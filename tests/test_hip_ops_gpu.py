@@ -176,7 +176,7 @@ def test_conv_every_launch_plan(name, g):
     dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
     dw_ref = TB.conv_wgrad(x, dy, g, bn_in=bn)
     xd, wd, dyd, bnd = x.to(DEV), wp.to(DEV), dy.to(DEV), to_dev(bn)
-    for tile in range(8):
+    for tile in range(12):
         for split in (1, 2, 5, 16):
             with ops.force_plan(tile, split):
                 st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
@@ -194,7 +194,7 @@ def test_conv_every_launch_plan(name, g):
                 dw = ops.conv_wgrad(xd, dyd, g, bn_in=bnd)
             check(f"plan/{name}/wgrad_t{tile}s{split}", dw, dw_ref, rtol=5e-4, atol_rel=5e-4)
     with pytest.raises(ops.MopoeHipError):
-        with ops.force_plan(9, 1):
+        with ops.force_plan(13, 1):
             ops.conv_fwd(xd, wd, g)
 
 
