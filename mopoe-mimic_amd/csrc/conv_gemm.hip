@@ -124,6 +124,33 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
   return v;
 }
 
+// ---- which taps a block multiplies, and from where --------------------------------------------------------------
+// form 0: every tap, source pixel = output pixel * stride - pad + tap.  form 1 (sub-pixel phase `phase` of the big
+// grid): only the taps congruent to the phase, source pixel = (output pixel + pad - tap) / stride, walked backwards.
+struct TapWalk {
+  int nty, ntx;          // taps of this phase along y / x
+  int ky0, kx0;          // first tap
+  int kstep_y, kstep_x;  // tap stride
+  int dsgn;              // +1: source moves forward with the tap, -1: backward
+  int cy, cx;            // source offset of the first tap (form 1)
+  int phy, phx;          // the phase (form 1)
+};
+__device__ __forceinline__ TapWalk tap_walk(const GemmArgs& a, int phase) {
+  TapWalk w;
+  w.cy = w.cx = w.phy = w.phx = 0;
+  if (a.form == 0) {
+    w.nty = a.kh; w.ntx = a.kw; w.ky0 = 0; w.kx0 = 0; w.kstep_y = 1; w.kstep_x = 1; w.dsgn = 1;
+  } else {
+    w.phy = phase / a.sw; w.phx = phase % a.sw;
+    const int ry = (w.phy + a.ph) % a.sh, rx = (w.phx + a.pw) % a.sw;
+    w.nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
+    w.ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
+    w.ky0 = ry; w.kx0 = rx; w.kstep_y = a.sh; w.kstep_x = a.sw; w.dsgn = -1;
+    w.cy = (w.phy + a.ph - ry) / a.sh; w.cx = (w.phx + a.pw - rx) / a.sw;
+  }
+  return w;
+}
+
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile of 32x32 MFMA tiles.
 // SPEC fixes the three mode flags of the main loop at compile time (0 = all of them at run time):
@@ -160,18 +187,9 @@ void gather_gemm_kernel(const GemmArgs a) {
   const int phase = blockIdx.z / a.nsplit;
   const int split = blockIdx.z - phase * a.nsplit;
 
-  // ---- phase / tap enumeration ---------------------------------------------------------------
-  int nty, ntx, ky0, kx0, kstep_y, kstep_x, dsgn, cy = 0, cx = 0, phy = 0, phx = 0;
-  if (a.form == 0) {
-    nty = a.kh; ntx = a.kw; ky0 = 0; kx0 = 0; kstep_y = 1; kstep_x = 1; dsgn = 1;
-  } else {
-    phy = phase / a.sw; phx = phase % a.sw;
-    const int ry = (phy + a.ph) % a.sh, rx = (phx + a.pw) % a.sw;
-    nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
-    ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
-    ky0 = ry; kx0 = rx; kstep_y = a.sh; kstep_x = a.sw; dsgn = -1;
-    cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
-  }
+  const TapWalk tw = tap_walk(a, phase);
+  const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
+  const int dsgn = tw.dsgn, cy = tw.cy, cx = tw.cx, phy = tw.phy, phx = tw.phx;
   const int nkc = (a.Ck + GBK - 1) / GBK;
   const int total_all = nty * ntx * nkc;
   // buffer descriptors (wave-uniform: kernel arguments only) for the branch-free vector path
@@ -503,17 +521,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (TI * TJ >= 4 ? 3 : 4)) void direct
   const int phase = blockIdx.z / a.nsplit;
   const int split = blockIdx.z - phase * a.nsplit;
 
-  int nty, ntx, ky0, kx0, kstep_y, kstep_x, dsgn, cy = 0, cx = 0, phy = 0, phx = 0;
-  if (a.form == 0) {
-    nty = a.kh; ntx = a.kw; ky0 = 0; kx0 = 0; kstep_y = 1; kstep_x = 1; dsgn = 1;
-  } else {
-    phy = phase / a.sw; phx = phase % a.sw;
-    const int ry = (phy + a.ph) % a.sh, rx = (phx + a.pw) % a.sw;
-    nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
-    ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
-    ky0 = ry; kx0 = rx; kstep_y = a.sh; kstep_x = a.sw; dsgn = -1;
-    cy = (phy + a.ph - ry) / a.sh; cx = (phx + a.pw - rx) / a.sw;
-  }
+  const TapWalk tw = tap_walk(a, phase);
+  const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
+  const int dsgn = tw.dsgn, cy = tw.cy, cx = tw.cx, phy = tw.phy, phx = tw.phx;
   const int nkc = a.Ck / KS;                     // Ck % 8 == 0 (host)
   const int total_all = nty * ntx * nkc;
   const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
