@@ -38,10 +38,11 @@ CONFIGS = {
     "c1": (64, 64, 64, 8),
     "c2": (128, 128, 64, 64),
     "c5": (256, 256, 64, 32),
+    "c2b256": (128, 128, 64, 256),   # config #3's batch at fp32 (there is no bf16 path)
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 # conv/linear FLOPs per sample per train step (fwd + dgrad + wgrad)
-FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c5": 42.63e9}
+FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c5": 42.63e9, "c2b256": 13.58e9}
 
 
 def synthetic_batches(flags, n, device, seed):
