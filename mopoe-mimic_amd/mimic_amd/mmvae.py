@@ -26,6 +26,9 @@ MOD_SLOT = {"PA": 0, "Lateral": 1, "text": 2}
 # none of which fills 256 CUs) overlap with the other modalities' work.  Autograd replays each network's
 # backward on the stream its forward ran on.  MOPOE_NET_STREAMS=0 keeps everything on the caller's stream.
 NET_STREAMS = os.environ.get("MOPOE_NET_STREAMS", "1") != "0"
+# which modalities get a stream of their own (the others stay on the caller's stream).  Default: the two image
+# modalities fork, text runs in line -- one fork/join pair less per phase; measured +1.7 % over forking all three
+NET_STREAM_SET = set(os.environ.get("MOPOE_NET_STREAM_SET", "PA,Lateral").split(","))
 _net_streams: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
 
 
@@ -43,7 +46,7 @@ class _ModalityLanes:
             self.ev.record(self.main)
 
     def fork(self, name):
-        if not self.enabled:
+        if not self.enabled or name not in NET_STREAM_SET:
             return contextlib.nullcontext()
         key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), name)
         if key not in _net_streams:
