@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      the dominant kernel (fp32-MFMA implicit-GEMM) timed with HIP events on its launch stream
                 in a second pass of the same steps (so the events do not perturb `value`)
   cpu_baseline  the CPU oracle (oracle/mopoe_ref.py, a port) timed on this host's cores on a bounded
-                sample (1 warm-up + 1 timed step of the same workload, ~35 s of CPU work).
+                sample (1 warm-up + 3 timed steps of the same workload on 16 threads, ~30 s of CPU work).
 """
 import argparse
 import json
@@ -57,11 +57,16 @@ def synthetic_batches(flags, n, device, seed):
     return out
 
 
-def cpu_baseline(cfg_name, steps=1):
-    """CPU restatement (oracle) of the same train step on this host: fwd + autograd bwd + Adam."""
+def cpu_baseline(cfg_name, steps=3, threads=None):
+    """CPU restatement (oracle) of the same train step on this host: fwd + autograd bwd + Adam.  Threads: the box's
+    CPU share for one GPU (16) unless the host has fewer cores -- 128 oversubscribed threads were SLOWER than the
+    reference's own 8-thread figure."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import mopoe_ref as R
-    size, cdim, dimg, bsz = CONFIGS[cfg_name]
+    host_cores = os.cpu_count() or 1
+    threads = threads or int(os.environ.get("MOPOE_CPU_THREADS", min(16, host_cores)))
+    torch.set_num_threads(threads)
+    size, cdim, dimg, bsz = CONFIGS[cfg_name][:4]
     cfg = R.Cfg(img_size=size, class_dim=cdim, DIM_img=dimg, DIM_text=128, vocab_size=3517, batch_size=bsz)
     torch.manual_seed(0)
     sd = R.leaf_state(R.init_state(cfg, seed=0))
@@ -79,16 +84,18 @@ def cpu_baseline(cfg_name, steps=1):
         R.adam_train_step(cfg, sd, opt, batch, eps, R.Ctx("train", draw_masks=True))
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / steps
-    return {"value": bsz / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} step(s) (after 1 warm-up) of the same workload (B={bsz}) through oracle/mopoe_ref.py: "
-                      f"fwd + autograd bwd + Adam, {t:.2f} s/step"}
+    return {"value": bsz / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "host_cores": host_cores,
+            "kind": "port",
+            "sample": f"{steps} timed steps (after 1 warm-up) of the same workload (B={bsz}, fp32) through "
+                      f"oracle/mopoe_ref.py on {torch.get_num_threads()} threads: fwd + autograd bwd + Adam, {t:.2f} s/step "
+                      f"(per step: {', '.join(f'{x:.2f}' for x in times[1:])} s)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)    # >= 20 warm-up + >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

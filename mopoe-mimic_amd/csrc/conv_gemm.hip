@@ -1250,6 +1250,8 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   a.fast = (vec && ((g->Ws % BK == 0) || (BK % g->Ws == 0 && hw_s % BK == 0))) ? 1 : 0;
   const int taps = g->kh * g->kw;
   bool big = g->Cin > 64 && g->Cout > 64;
+  if (plan && plan->tile == 2) big = false;   // the plan may ask for 64x64 tiles on wide layers too (tile 0 = 128x128 needs both > 64)
+  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0 or 2)", plan->tile); return MOPOE_ERR_ARG; }
   const int T = big ? 128 : 64;
   const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
   a.nJ = nJ;

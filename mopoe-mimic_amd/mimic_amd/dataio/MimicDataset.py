@@ -31,4 +31,5 @@ class Mimic_testing(Dataset):
         return {"PA": torch.rand(1, *size).float(), "Lateral": torch.rand(1, *size).float()}
 
     def __len__(self) -> int:
-        return 2 * self.flags.batch_size
+        # the reference's 2 batches; flags.testing_batches lengthens the synthetic epoch (launcher tests, rate measurements)
+        return int(getattr(self.flags, "testing_batches", 2)) * self.flags.batch_size

@@ -104,6 +104,14 @@ class BnParams(nn.Module):
             self.pending_batches = 0
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        # the loaded num_batches_tracked is the whole truth: batches counted on the host before the load belong to the
+        # state that is being replaced
+        self.pending_batches = 0
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
 
 class Indexed(nn.Module):
     """Container whose children are named '0', '1', ... (the key scheme nn.Sequential produces)."""

@@ -33,7 +33,8 @@ class GradAllReducer:
         """force: run the collectives even with a single rank (rehearsal of the RCCL path on a 1-GPU box)"""
         self.module, self.world_size = module, world_size
         self.active = world_size > 1 or (force and dist.is_initialized())
-        self._pending = []       # (work handle, arena)
+        self._pending = []       # (work handle or None, arena, addresses of the gradients the backward node returned)
+        self._adopted = False    # autograd has been SEEN to adopt the arena views as param.grad (checked every step)
         self._avg = None
         self._deferred = None    # list of arenas while a step is being captured into a hipGraph (no collectives inside)
         if self.active:
@@ -76,7 +77,15 @@ class GradAllReducer:
         if self._deferred is not None:
             self._deferred.append(arena)
             return
-        self._pending.append((self._launch(arena), arena))
+        # Reducing the arena IN PLACE from inside the backward node, before AccumulateGrad has run, is only correct if
+        # autograd then adopts these views as param.grad without copying (it does after zero_grad(set_to_none=True)).
+        # Were it to clone instead, the clone would read the arena while the collective rewrites it.  So the early
+        # launch is used only once adoption has been observed (all_reduce_grads checks it on every step, and raises if
+        # it ever stops holding); until then the collective is deferred to all_reduce_grads.
+        # (only the ADDRESSES of the returned gradients are kept: a second reference to a gradient tensor would itself
+        # make AccumulateGrad clone it instead of adopting it)
+        work = self._launch(arena) if self._adopted else None
+        self._pending.append((work, arena, [g.data_ptr() for g in grads]))
 
     # ---- graphed steps (run_epochs.GraphedTrainStep): forward + backward live in one hipGraph, the collectives run
     # eagerly between that graph and the optimiser graph, on the arenas' fixed addresses
@@ -108,11 +117,22 @@ class GradAllReducer:
         if not self.active:
             return
         ranges = []
-        for work, t in self._pending:
+        held = {p.grad.data_ptr() for p in self.module.parameters() if p.grad is not None}
+        adopted = all(ptr in held for _w, _t, ptrs in self._pending for ptr in ptrs)
+        if self._adopted and not adopted:
+            raise RuntimeError("data-parallel overlap: autograd copied a gradient out of a network arena after the "
+                               "arena's all-reduce had been started from the backward node; the averaged gradients "
+                               "would be wrong (a hook / create_graph / layout change?)")
+        for work, t, _grads in self._pending:
+            if work is None and not adopted:
+                continue          # its gradients were copied out: they travel in the flat bucket below
+            if work is None:
+                work = self._launch(t)
             work.wait()
             if self._avg is None:
                 t.div_(self.world_size)
             ranges.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+        self._adopted = adopted and bool(self._pending)
         self._pending.clear()
         outside = [p.grad for p in self.module.parameters()
                    if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]

@@ -11,8 +11,11 @@ run_epochs :231-272), re-designed around the device:
 """
 from __future__ import annotations
 
+import os
 import random
+import time
 import typing
+import warnings
 from contextlib import contextmanager
 
 import numpy as np
@@ -61,13 +64,20 @@ def basic_routine_epoch(exp, batch) -> typing.Mapping[str, any]:
 
 
 class ScalarPack:
-    """Device-side pack of the per-step logging scalars + one async D2H copy into pinned memory."""
+    """Device-side pack of the per-step logging scalars + one async D2H copy into pinned memory.
+
+    Two pinned buffers alternate, so the scalars of step i-1 can be read on the host AFTER step i has been enqueued
+    (the GPU never idles behind the read) without step i's copy overwriting them.  Inside a hipGraph capture only the
+    device-side pack is recorded (its address is static); the replaying caller issues the copy-out with flush()."""
 
     def __init__(self, device):
         self.device = device
-        self.host = None
+        self.host = [None, None]
+        self.events = [None, None]
+        self.slot = 0
+        self.submitted = 0
         self.names: typing.List[str] = []
-        self.event = None
+        self.static = None     # the captured device-side pack of a GraphedTrainStep
 
     def submit(self, routine, reducer: typing.Optional["GradAllReducer"] = None):
         res = routine["results"]
@@ -85,29 +95,38 @@ class ScalarPack:
             names += [f"latents/{k}/mu", f"latents/{k}/logvar"]
             vals += [mu.detach().mean().reshape(1), lv.detach().mean().reshape(1)]
         packed = torch.cat(vals)
+        self.names = names
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self.static = packed     # copied out per replay by flush()
+            return
         if reducer is not None and reducer.active:
             packed = reducer.mean_scalars(packed)
-        if self.host is None or self.host.numel() != packed.numel():
-            self.host = torch.empty(packed.numel(), dtype=torch.float32,
-                                    pin_memory=(self.device.type == "cuda"))
-        self.host.copy_(packed, non_blocking=True)
-        self.names = names
-        if self.device.type == "cuda":
-            if torch.cuda.is_current_stream_capturing():
-                self.event = None       # a captured step is read back after a stream synchronise (GraphedTrainStep)
-                self.stream = torch.cuda.current_stream()
-            else:
-                self.event = torch.cuda.Event()
-                self.event.record()
+        self._copy_out(packed)
 
-    def read(self) -> typing.Dict[str, float]:
-        if self.host is None:   # nothing submitted yet
+    def _copy_out(self, packed):
+        self.slot ^= 1
+        k = self.slot
+        if self.host[k] is None or self.host[k].numel() != packed.numel():
+            self.host[k] = torch.empty(packed.numel(), dtype=torch.float32, pin_memory=(self.device.type == "cuda"))
+        self.host[k].copy_(packed, non_blocking=True)
+        if self.device.type == "cuda":
+            self.events[k] = torch.cuda.Event()
+            self.events[k].record()
+        self.submitted += 1
+
+    def flush(self):
+        """after a replay of the graph that recorded `static`: copy the scalars out (current stream)"""
+        if self.static is not None:
+            self._copy_out(self.static)
+
+    def read(self, previous: bool = False) -> typing.Dict[str, float]:
+        """scalars of the latest submitted step (previous=True: of the one before it)"""
+        if self.submitted < (2 if previous else 1):
             return {}
-        if self.event is not None:
-            self.event.synchronize()
-        elif getattr(self, "stream", None) is not None:
-            self.stream.synchronize()
-        return dict(zip(self.names, self.host.tolist()))
+        k = self.slot ^ 1 if previous else self.slot
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        return dict(zip(self.names, self.host[k].tolist()))
 
 
 def train_step(exp, batch, reducer=None, pack: typing.Optional[ScalarPack] = None):
@@ -204,38 +223,97 @@ class GraphedTrainStep:
             self.graph_opt.replay()
             if self.pack is not None:
                 self.pack.submit(self.routine, self.reducer)
-        elif self.pack is not None and self.pack.device.type == "cuda":   # read-back fence on the replaying stream
-            self.pack.event = torch.cuda.Event()
-            self.pack.event.record()
+        elif self.pack is not None:   # the captured step packed its scalars on the device: copy them out
+            self.pack.flush()
         for m, d in self._bn_bump:
             m.pending_batches += d
         return self.routine
 
 
+USE_GRAPH = os.environ.get("MOPOE_GRAPH", "1") != "0"
+
+
+def _batch_signature(batch_d):
+    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch_d.items()))
+
+
+class _StepRunner:
+    """What train() drives: the captured step (GraphedTrainStep) whenever the batch has the captured shapes, the eager
+    train_step otherwise (ragged last batch of an epoch, a runtime that refuses the capture, CPU tensors, MOPOE_GRAPH=0).
+    One runner lives on the experiment across epochs, so the capture happens once per run."""
+
+    def __init__(self, exp, reducer, pack):
+        self.exp, self.reducer, self.pack = exp, reducer, pack
+        self.graphed, self.signature, self.failed = None, None, False
+        self.n_graphed = self.n_eager = 0
+
+    def graph_allowed(self):
+        opt = self.exp.optimizer
+        return (USE_GRAPH and not self.failed and self.exp.flags.device.type == "cuda"
+                and bool(opt.defaults.get("capturable", False)))
+
+    def __call__(self, batch):
+        batch_d = {k: v.to(self.exp.flags.device, non_blocking=True) for k, v in batch[0].items()}
+        sig = _batch_signature(batch_d)
+        if self.graphed is None and self.graph_allowed() and sig[0][1][0] == self.exp.flags.batch_size:
+            try:
+                # (its set-up runs eager steps on this batch: they are ordinary optimiser steps of the epoch)
+                self.graphed = GraphedTrainStep(self.exp, (batch_d, None), self.pack, self.reducer, warmup=1)
+                self.signature = sig
+                self.n_eager += 1
+                return
+            except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
+                if isinstance(e, torch.cuda.OutOfMemoryError) or str(e).startswith(("HIP out of memory", "CUDA out of memory")):
+                    raise
+                self.failed, self.graphed = True, None
+                warnings.warn(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eager steps")
+        if self.graphed is not None and sig == self.signature:
+            self.graphed((batch_d, None))
+            self.n_graphed += 1
+        else:
+            train_step(self.exp, (batch_d, None), self.reducer, self.pack)
+            self.n_eager += 1
+
+
 def train(exp, train_loader, reducer=None, max_steps=None):
-    """Returns the last step's scalars, like the reference's meters do (AverageMeter.get_average
-    returns the last value, average_meters.py:33-34) plus running means of the dict-valued meters."""
+    """One training epoch (reference run_epochs.train :99-145).  Returns the last step's scalars, like the reference's
+    meters do (AverageMeter.get_average returns the last value, average_meters.py:33-34), plus running means.
+
+    The step is the captured hipGraph whenever shapes allow (what bench.py times); the scalars of step i-1 are read
+    on the host after step i has been enqueued, so the device never waits for the host's read."""
     exp.mm_vae.train()
-    pack = ScalarPack(exp.flags.device)
+    runner = getattr(exp, "_step_runner", None)
+    if runner is None or runner.reducer is not reducer or runner.exp is not exp:
+        runner = _StepRunner(exp, reducer, ScalarPack(exp.flags.device))
+        exp._step_runner = runner
+    pack = runner.pack
     sums, n, last = {}, 0, {}
-    steps = exp.flags.steps_per_training_epoch if 0 < exp.flags.steps_per_training_epoch else max_steps
-    for it, batch in enumerate(train_loader):
-        if steps and it >= steps:
-            break
-        if n:  # read the PREVIOUS step's scalars while this step is being enqueued
-            last = pack.read()
-            _check_nan(exp, last)
-            for k, v in last.items():
-                sums[k] = sums.get(k, 0.0) + v
-        train_step(exp, batch, reducer, pack)
-        n += 1
+    nloader = len(train_loader) if hasattr(train_loader, "__len__") else None
+    steps = exp.flags.steps_per_training_epoch
+    if not (0 < steps and (nloader is None or steps < nloader)):
+        steps = max_steps
+
+    def account(scalars):
+        _check_nan(exp, scalars)
+        for k, v in scalars.items():
+            sums[k] = sums.get(k, 0.0) + v
+
+    g0, t0 = runner.n_graphed, time.perf_counter()
+    with catching_cuda_out_of_memory(exp.flags.batch_size):
+        for it, batch in enumerate(train_loader):
+            if steps and it >= steps:
+                break
+            runner(batch)
+            n += 1
+            if n > 1:   # step i is enqueued: now read step i-1 (double-buffered pinned pack)
+                account(pack.read(previous=True))
     if n:
         last = pack.read()
-        _check_nan(exp, last)
-        for k, v in last.items():
-            sums[k] = sums.get(k, 0.0) + v
+        account(last)
+    elapsed = time.perf_counter() - t0      # (the last read waited for the last step's scalars: the epoch is complete)
     means = {k: v / max(n, 1) for k, v in sums.items()}
-    return {"last": last, "mean": means, "steps": n}
+    return {"last": last, "mean": means, "steps": n, "graphed_steps": runner.n_graphed - g0, "seconds": elapsed,
+            "samples_per_sec": n * exp.flags.batch_size / max(elapsed, 1e-9)}
 
 
 def _check_nan(exp, scalars):
@@ -257,20 +335,110 @@ def test(epoch, exp, test_loader, max_steps=None):
                 break
             routine = basic_routine_epoch(exp, batch)
             pack.submit(routine)
-            for k, v in pack.read().items():
-                out[k] = out.get(k, 0.0) + v
             n += 1
+            if n > 1:   # batch i is enqueued: read batch i-1
+                for k, v in pack.read(previous=True).items():
+                    out[k] = out.get(k, 0.0) + v
+    if n:
+        for k, v in pack.read().items():
+            out[k] = out.get(k, 0.0) + v
     return {k: v / max(n, 1) for k, v in out.items()}
 
 
-def run_epochs(rank, exp, train_loader_fn, epochs: int, world_size: int = 1):
-    """One process per GPU.  ``train_loader_fn(rank, world_size)`` yields ((dict, labels)) batches."""
+class Callbacks:
+    """Hot-path subset of the reference's Callbacks (mimic/utils/experiment.py:286-402): ReduceLROnPlateau on the test
+    loss, the early-stopping bookkeeping and the checkpoint rule (every 50 epochs and at end_epoch, rank 0 only:
+    save_networks() + the whole model's state_dict under dir_checkpoints/<epoch:04d>/<mm_vae_save>).  TensorBoard,
+    the experiments dataframe and the metric plots are outside the hot path."""
+
+    def __init__(self, exp):
+        from torch.optim.lr_scheduler import ReduceLROnPlateau
+        self.args, self.exp = exp.flags, exp
+        self.start_early_stopping_epoch = getattr(self.args, "start_early_stopping_epoch", 0)
+        self.max_early_stopping_index = getattr(self.args, "max_early_stopping_index", 5)
+        self.losses = [float("inf")]
+        self.patience_idx = 1
+        self.scheduler = ReduceLROnPlateau(exp.optimizer, "min", patience=5)
+        self.elapsed_times = []
+
+    def update_epoch(self, epoch, test_results, elapsed_time) -> bool:
+        loss = test_results["total_loss"]
+        stop_early = False
+        self.elapsed_times.append(elapsed_time)
+        self.scheduler.step(loss)
+        self.save_checkpoint(epoch)
+        if epoch > self.start_early_stopping_epoch and loss < min(self.losses):
+            self.patience_idx = 1
+        elif self.patience_idx > self.max_early_stopping_index:
+            stop_early = True
+        elif epoch > self.start_early_stopping_epoch:
+            self.patience_idx += 1
+        self.losses.append(loss)
+        return stop_early
+
+    def save_checkpoint(self, epoch):
+        f = self.exp.flags
+        rank0 = (not getattr(f, "distributed", False)) or _rank_of(f.device) % max(1, getattr(f, "world_size", 1)) == 0
+        if ((epoch + 1) % 50 == 0 or (epoch + 1) == f.end_epoch) and rank0:
+            dir_network_epoch = os.path.join(str(f.dir_checkpoints), str(epoch).zfill(4))
+            os.makedirs(dir_network_epoch, exist_ok=True)
+            self.exp.mm_vae.save_networks()
+            torch.save(self.exp.mm_vae.state_dict(), os.path.join(dir_network_epoch, getattr(f, "mm_vae_save", "mm_vae")))
+
+
+def _rank_of(device) -> int:
+    if isinstance(device, int):
+        return device
+    return device.index if getattr(device, "index", None) is not None else 0
+
+
+def set_up_process_group(world_size: int, rank: int) -> None:
+    """mimic/utils/utils.py:179-185 with RCCL over xGMI ('nccl' on ROCm) instead of gloo, one process per GPU."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "12355")
+    backend = os.environ.get("MOPOE_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", world_size=world_size, rank=rank, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group(backend, world_size=world_size, rank=rank)
+
+
+def run_epochs(rank, exp) -> typing.List[dict]:
+    """mimic/run_epochs.py:231-272: `rank` is the GPU index under one-process-per-GPU data parallelism and a
+    torch.device otherwise.  Seeds, optimiser, (process group + gradient all-reducer in place of DDP), loaders from
+    exp.dataset_train / exp.dataset_test, then per epoch: train(), test(), Callbacks.update_epoch (LR schedule, early
+    stopping, checkpoint).  Returns the per-epoch results (the reference returns None)."""
+    import torch.distributed as dist
+    from .dataio.utils import PrefetchToDevice, get_data_loaders, samplers_set_epoch
     set_random_seed(exp.flags.seed)
+    args = exp.flags
+    args.device = torch.device("cuda", rank) if isinstance(rank, int) else torch.device(rank)
+    if args.device.type == "cuda":
+        torch.cuda.set_device(args.device)
+    exp.mm_vae = exp.mm_vae.to(args.device)
     exp.set_optimizer()
-    reducer = GradAllReducer(exp.mm_vae, world_size) if world_size > 1 else None
-    if reducer is not None:
+    reducer = None
+    if getattr(args, "distributed", False):
+        if not dist.is_initialized():
+            set_up_process_group(args.world_size, _rank_of(rank))
+        reducer = GradAllReducer(exp.mm_vae, args.world_size)
         reducer.broadcast_parameters()
+    train_sampler, train_loader = get_data_loaders(args, exp.dataset_train, which_set="train",
+                                                   weighted_sampler=getattr(args, "weighted_sampler", False))
+    test_sampler, test_loader = get_data_loaders(args, exp.dataset_test, which_set="eval")
+    callbacks = Callbacks(exp)
     history = []
-    for epoch in range(epochs):
-        history.append(train(exp, train_loader_fn(rank, world_size), reducer))
+    for epoch in range(getattr(args, "start_epoch", 0), args.end_epoch):
+        end = time.time()
+        samplers_set_epoch(args, train_sampler, test_sampler, epoch)
+        tr = train(exp, PrefetchToDevice(train_loader, args.device), reducer)
+        if reducer is not None:
+            reducer.sync_buffers()       # running statistics are per rank during training; rank 0's are evaluated / saved
+        test_results = test(epoch, exp, PrefetchToDevice(test_loader, args.device))
+        history.append({"epoch": epoch, "train": tr, "test": test_results, "seconds": time.time() - end})
+        if callbacks.update_epoch(epoch, test_results, time.time() - end):
+            break
+    if getattr(args, "distributed", False) and dist.is_initialized():
+        dist.destroy_process_group()
     return history

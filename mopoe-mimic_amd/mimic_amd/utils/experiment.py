@@ -27,7 +27,11 @@ def default_flags(**overrides) -> argparse.Namespace:
         div_weight_uniform_content=0.25, div_weight_m1_content=0.25, div_weight_m2_content=0.25,
         div_weight_m3_content=0.25, rec_weight_m1=0.33, rec_weight_m2=0.33, rec_weight_m3=0.33,
         initial_learning_rate=5e-4, beta_1=0.9, beta_2=0.999, dataset="testing", distributed=False,
-        steps_per_training_epoch=0, seed=0, device=torch.device("cuda" if torch.cuda.is_available() else "cpu"),
+        steps_per_training_epoch=0, seed=0,
+        # (evaluated only when the caller passes no device: a launcher process must not initialise the GPU)
+        device=overrides["device"] if "device" in overrides else torch.device("cuda" if torch.cuda.is_available() else "cpu"),
+        start_epoch=0, end_epoch=1, eval_freq=10, world_size=1, dataloader_workers=0, weighted_sampler=False,
+        mm_vae_save="mm_vae", start_early_stopping_epoch=0, max_early_stopping_index=5, testing_batches=2,
         encoder_save_m1="encoderM1", encoder_save_m2="encoderM2", encoder_save_m3="encoderM3",
         decoder_save_m1="decoderM1", decoder_save_m2="decoderM2", decoder_save_m3="decoderM3",
         dir_checkpoints=".")
@@ -50,6 +54,15 @@ class HotPathExperiment:
         self.optimizer = None
         self.rec_weights = self.set_rec_weights()
         self.style_weights = {"PA": flags.beta_m1_style, "Lateral": flags.beta_m2_style, "text": flags.beta_m3_style}
+        self.dataset_train, self.dataset_test = self.set_dataset()
+
+    def set_dataset(self):
+        """mimic/utils/experiment.py:106-123: dataset 'testing' = the synthetic Mimic_testing pair; the real MIMIC-CXR
+        tensor files are absent from the reference checkout."""
+        from ..dataio.MimicDataset import Mimic_testing
+        if self.flags.dataset != "testing":
+            raise NotImplementedError("only dataset='testing' (synthetic Mimic_testing) is available to the hot path")
+        return Mimic_testing(self.flags), Mimic_testing(self.flags)
 
     def set_modalities(self):
         f = self.flags
@@ -69,17 +82,26 @@ class HotPathExperiment:
     def set_model(self):
         return VAEtrimodalMimic(self.flags, self.modalities, self.subsets)
 
-    def set_optimizer(self, capturable: bool = False):
+    def set_optimizer(self, capturable=None):
         params = list(self.mm_vae.parameters())
         # same Adam arithmetic as the reference's optim.Adam (experiment.py:171-178); the fused
         # multi-tensor implementation updates all ~370 tensors in a handful of launches.
-        # capturable: step counters live on the device so that the step can sit inside a hipGraph
-        # (run_epochs.GraphedTrainStep)
-        fused = all(p.is_cuda for p in params)
-        self.optimizer = optim.Adam(params, lr=self.flags.initial_learning_rate,
-                                    betas=(self.flags.beta_1, self.flags.beta_2), fused=fused,
-                                    capturable=bool(capturable and fused))
+        # capturable (default on the GPU): step counters AND the learning rate live on the device, so the step can sit
+        # inside a hipGraph (run_epochs.GraphedTrainStep) and a scheduler's lr change (Callbacks' ReduceLROnPlateau
+        # fills the tensor in place) reaches the captured optimiser without a re-capture
+        fused = bool(params) and all(p.is_cuda for p in params)
+        if capturable is None:
+            capturable = fused
+        capturable = bool(capturable and fused)
+        lr = self.flags.initial_learning_rate
+        if capturable:
+            lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
+        self.optimizer = optim.Adam(params, lr=lr, betas=(self.flags.beta_1, self.flags.beta_2), fused=fused,
+                                    capturable=capturable)
 
     def set_rec_weights(self):
         f = self.flags
         return {"PA": f.rec_weight_m1, "Lateral": f.rec_weight_m2, "text": f.rec_weight_m3}
+
+
+MimicExperiment = HotPathExperiment   # the reference's class name (mimic/utils/experiment.py:41)

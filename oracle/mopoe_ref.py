@@ -191,12 +191,56 @@ class Ctx:
     """Execution context: mode + injected dropout masks + (optional) capture of new BN running stats."""
 
     def __init__(self, mode: str = "train_nodrop", masks: Optional[Dict[str, torch.Tensor]] = None,
-                 draw_masks: bool = False):
+                 draw_masks: bool = False, record_masks: bool = False, mask_seed: Optional[int] = None,
+                 bf16: bool = False):
         assert mode in ("train", "train_nodrop", "eval")
         self.mode = mode
-        self.masks = masks or {}
-        self.draw_masks = draw_masks  # used only by the CPU timing baseline
+        self.masks = masks if masks is not None else {}
+        self.draw_masks = draw_masks  # the CPU timing baseline, and tests that need masks at sizes no fixture holds
+        self.record_masks = record_masks  # keep the drawn masks in self.masks (replayed into the HIP path by tests)
+        self.mask_gen = torch.Generator().manual_seed(mask_seed) if mask_seed is not None else None
+        # bf16 = the storage/operand rounding of the HIP bf16 path (BASELINE configs #3, #5): every activation the
+        # kernels keep in HBM and every MFMA operand (activations after BN+ReLU, conv/linear weights) is rounded to
+        # bfloat16, all sums stay fp32 -- the reference arithmetic with the product's rounding points, see _q()
+        self.bf16 = bf16
         self.new_running: Dict[str, torch.Tensor] = {}
+
+
+class _RoundBf16(torch.autograd.Function):
+    """x -> bf16(x) (round to nearest even) kept in the working dtype; the gradient passing back through the same
+    point is rounded too (the HIP bf16 path stores activation gradients in bf16 at the same places)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _GradRoundBf16(torch.autograd.Function):
+    """identity whose gradient is rounded to bf16 (a gradient tensor the bf16 path stores, of an fp32 activation)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _q(x, ctx: "Ctx"):
+    return _RoundBf16.apply(x) if ctx.bf16 else x
+
+
+def _qw(w, ctx: "Ctx"):
+    """weights as the bf16 MFMA operand (the fp32 master copy receives the unrounded gradient)"""
+    if not ctx.bf16:
+        return w
+    wd = w.detach()
+    return w + (wd.to(torch.bfloat16).to(w.dtype) - wd)   # value: bf16(w); gradient: straight through to w
 
 
 def _bn(sd, key, x, ctx: Ctx):
@@ -228,7 +272,10 @@ def _drop(x, key, ctx: Ctx, channelwise: bool):
         return x * ctx.masks[key].to(x.dtype)
     if ctx.draw_masks:
         shape = (x.shape[0], x.shape[1], 1, 1) if channelwise else x.shape
-        return x * (torch.rand(shape) < 0.5).to(x.dtype) * 2.0
+        m = (torch.rand(shape, generator=ctx.mask_gen) < 0.5).to(x.dtype) * 2.0
+        if ctx.record_masks:
+            ctx.masks[key] = m
+        return x * m
     raise KeyError(f"train mode needs a dropout mask for {key}")
 
 
@@ -239,38 +286,43 @@ def _resblock(sd, prefix, x, ctx: Ctx, *, stride, pad, transposed, twod, short_n
         convf = F.conv_transpose2d if transposed else F.conv2d
     else:
         convf = F.conv_transpose1d if transposed else F.conv1d
-    h = F.relu(_bn(sd, prefix + ".bn1", x, ctx))
-    h = convf(h, sd[prefix + ".conv1.weight"], sd.get(prefix + ".conv1.bias"))
-    h = _drop(h, prefix + ".dropout1", ctx, twod)
-    h = F.relu(_bn(sd, prefix + ".bn2", h, ctx))
-    h = convf(h, sd[prefix + ".conv2.weight"], sd.get(prefix + ".conv2.bias"), stride=stride, padding=pad)
-    h = _drop(h, prefix + ".dropout2", ctx, twod)
-    s = convf(x, sd[prefix + f".{short_name}.0.weight"], sd[prefix + f".{short_name}.0.bias"],
-              stride=stride, padding=pad)
+    # ctx.bf16: x arrives rounded (it is a stored tensor); the conv operands relu(bn(.)) and the weights are rounded
+    # for the MFMA; d1 = drop1(conv1), m = drop2(conv2), s = conv_s and the block output are stored tensors
+    h = _q(F.relu(_bn(sd, prefix + ".bn1", x, ctx)), ctx)
+    h = convf(h, _qw(sd[prefix + ".conv1.weight"], ctx), sd.get(prefix + ".conv1.bias"))
+    h = _q(_drop(h, prefix + ".dropout1", ctx, twod), ctx)
+    h = _q(F.relu(_bn(sd, prefix + ".bn2", h, ctx)), ctx)
+    h = convf(h, _qw(sd[prefix + ".conv2.weight"], ctx), sd.get(prefix + ".conv2.bias"), stride=stride, padding=pad)
+    h = _q(_drop(h, prefix + ".dropout2", ctx, twod), ctx)
+    s = _q(convf(x, _qw(sd[prefix + f".{short_name}.0.weight"], ctx), sd[prefix + f".{short_name}.0.bias"],
+                 stride=stride, padding=pad), ctx)
     s = _bn(sd, prefix + f".{short_name}.1", s, ctx)
-    return RES_A * s + RES_B * h
+    return _q(RES_A * s + RES_B * h, ctx)
 
 
-def _compress(sd, prefix, feats):
+def _compress(sd, prefix, feats, ctx: Optional[Ctx] = None):
+    ctx = ctx or Ctx()
     feats = feats.reshape(feats.shape[0], -1)
-    mu = F.linear(feats, sd[prefix + ".content_mu.weight"], sd[prefix + ".content_mu.bias"])
-    lv = F.linear(feats, sd[prefix + ".content_logvar.weight"], sd[prefix + ".content_logvar.bias"])
+    # ctx.bf16: bf16 operands, fp32 results (mu / logvar feed the fp32 latent kernel unrounded)
+    mu = F.linear(feats, _qw(sd[prefix + ".content_mu.weight"], ctx), sd[prefix + ".content_mu.bias"])
+    lv = F.linear(feats, _qw(sd[prefix + ".content_logvar.weight"], ctx), sd[prefix + ".content_logvar.bias"])
     return mu, lv
 
 
 def encode_img(cfg: Cfg, sd, name: str, x, ctx: Ctx):
     """EncoderImg.forward (ConvNetworksImgMimic.py:29-36): x [B,1,S,S] -> (mu, logvar) [B,D]."""
     p = f"{name}.feature_extractor"
-    h = F.conv2d(x, sd[p + ".conv1.weight"], None, stride=2, padding=1)
+    # ctx.bf16: the single-channel stem runs on fp32 pixels and fp32 taps (streaming kernel); its output is stored bf16
+    h = _q(F.conv2d(x, sd[p + ".conv1.weight"], None, stride=2, padding=1), ctx)
     for i, (_ci, _co, s, pd) in enumerate(img_enc_blocks(cfg)):
         h = _resblock(sd, f"{p}.resblock_{i + 1}.0", h, ctx, stride=s, pad=pd, transposed=False,
                       twod=True, short_name="downsample")
-    return _compress(sd, f"{name}.feature_compressor", h)
+    return _compress(sd, f"{name}.feature_compressor", h, ctx)
 
 
 def decode_img(cfg: Cfg, sd, name: str, z, ctx: Ctx):
     """DecoderImg.forward (ConvNetworksImgMimic.py:46-54): z [B,D] -> img_hat [B,1,S,S]."""
-    h = F.linear(z, sd[f"{name}.feature_generator.weight"], sd[f"{name}.feature_generator.bias"])
+    h = _q(F.linear(_q(z, ctx), _qw(sd[f"{name}.feature_generator.weight"], ctx), sd[f"{name}.feature_generator.bias"]), ctx)
     h = h.view(h.shape[0], h.shape[1], 1, 1)
     p = f"{name}.img_generator.generator"
     blocks = img_dec_blocks(cfg)
@@ -285,21 +337,22 @@ def decode_img(cfg: Cfg, sd, name: str, z, ctx: Ctx):
 def encode_text(cfg: Cfg, sd, x_ids, ctx: Ctx):
     """EncoderText.forward (ConvNetworksTextMimic.py:23-36): float ids [B,L] -> (mu, logvar)."""
     p = "encoder_text.feature_extractor"
-    h = F.embedding(x_ids.long(), sd[p + ".embedding.weight"], padding_idx=0)
+    h = _q(F.embedding(x_ids.long(), sd[p + ".embedding.weight"], padding_idx=0), ctx)
     h = h.transpose(-2, -1)
-    h = F.conv1d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=2, padding=1)
+    h = _q(F.conv1d(h, _qw(sd[p + ".conv1.weight"], ctx), sd[p + ".conv1.bias"], stride=2, padding=1), ctx)
     blocks = text_enc_blocks(cfg)
     n_run = 8 if cfg.len_sequence > 500 else 6  # mmvae_text_enc.py:82-84
     for i in range(n_run):
         _ci, _co, s, pd = blocks[i]
         h = _resblock(sd, f"{p}.resblock_{i + 1}.0", h, ctx, stride=s, pad=pd, transposed=False,
                       twod=False, short_name="downsample")
-    return _compress(sd, "encoder_text.feature_compressor", h)
+    return _compress(sd, "encoder_text.feature_compressor", h, ctx)
 
 
 def decode_text(cfg: Cfg, sd, z, ctx: Ctx):
     """DecoderText.forward (ConvNetworksTextMimic.py:51-68): z -> log-probs [B,L,V]."""
-    h = F.linear(z, sd["decoder_text.feature_generator.weight"], sd["decoder_text.feature_generator.bias"])
+    h = _q(F.linear(_q(z, ctx), _qw(sd["decoder_text.feature_generator.weight"], ctx),
+                    sd["decoder_text.feature_generator.bias"]), ctx)
     h = h.unsqueeze(-1)
     p = "decoder_text.text_generator.generator"
     blocks = text_dec_blocks(cfg)
@@ -307,7 +360,10 @@ def decode_text(cfg: Cfg, sd, z, ctx: Ctx):
         h = _resblock(sd, f"{p}.{i}.0", h, ctx, stride=s, pad=pd, transposed=True, twod=False,
                       short_name="upsample")
     k = len(blocks)
-    logits = F.conv1d(h, sd[f"{p}.{k}.weight"], sd[f"{p}.{k}.bias"])
+    # ctx.bf16: bf16 operands, fp32 logits and log-probabilities; their gradient re-enters the GEMMs in bf16
+    logits = F.conv1d(h, _qw(sd[f"{p}.{k}.weight"], ctx), sd[f"{p}.{k}.bias"])
+    if ctx.bf16:
+        logits = _GradRoundBf16.apply(logits)
     return F.log_softmax(logits, dim=1).transpose(-2, -1)
 
 

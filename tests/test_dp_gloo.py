@@ -61,7 +61,28 @@ def _worker(rank, world, port, outdir):
     pack.submit(routine, reducer)
     scalars = pack.read()
     grads = {n: p.grad.clone() for n, p in exp.mm_vae.named_parameters() if p.grad is not None}
-    torch.save({"grads": grads, "scalars": scalars, "loss": routine["total_loss"].item()},
+    # Step 1 deferred every network's collective and OBSERVED that autograd adopted the arena views as param.grad;
+    # from step 2 on the collectives start inside the backward nodes (overlap).  Two more full steps: the overlapped
+    # form must keep the ranks' parameters identical, and every trunk gradient must live inside its network's arena.
+    adopted_after_1 = reducer._adopted
+    exp.optimizer.step()
+    inside = None
+    for _ in range(2):
+        routine2 = RE.basic_routine_epoch(exp, (batch, None))
+        exp.optimizer.zero_grad(set_to_none=True)
+        routine2["total_loss"].backward()
+        early = [w is not None for w, _t, _g in reducer._pending]
+        ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for _w, t, _g in reducer._pending]
+        import re
+        trunk = [p.grad for n, p in exp.mm_vae.named_parameters()
+                 if p.grad is not None and re.search(r"(resblock_\d+|generator\.\d+)\.0\.", n)]
+        assert len(trunk) > 300
+        inside = all(any(lo <= g.data_ptr() < hi for lo, hi in ranges) for g in trunk)
+        reducer.all_reduce_grads()
+        exp.optimizer.step()
+    chk = torch.cat([p.detach().double().flatten()[:64] for p in exp.mm_vae.parameters()])
+    torch.save({"grads": grads, "scalars": scalars, "loss": routine["total_loss"].item(),
+                "adopted_after_1": adopted_after_1, "early": early, "inside": inside, "chk": chk},
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -76,6 +97,12 @@ def test_two_ranks_equal_two_microbatches():
     # both ranks hold identical averaged gradients
     bad = [n for n, g in res[0]["grads"].items() if not torch.equal(g, res[1]["grads"][n])]
     assert not bad, bad[:8]
+    # eager overlap: adoption observed on step 1, collectives launched from the backward nodes afterwards, trunk
+    # gradients are views into the arenas, ranks stay bit-identical after three optimiser steps
+    for r in range(world):
+        assert res[r]["adopted_after_1"] is True and all(res[r]["early"]) and len(res[r]["early"]) == 6, res[r]["early"]
+        assert res[r]["inside"] is True
+    assert torch.equal(res[0]["chk"], res[1]["chk"])
     # single-process reference: rank-0 weights, the two shards as micro-batches, mean of the gradients
     _install_backend()
     from mimic_amd import run_epochs as RE

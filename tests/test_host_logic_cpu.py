@@ -113,6 +113,26 @@ def test_partial_modalities_inference(monkeypatch):
         close(lat["joint"][1], g[f"partial/{tag}/joint_logvar"])
 
 
+def test_g2_mixture_partition_product():
+    """The PRODUCT's batch partition (mimic_amd.mmvae.mixture_row_starts, the host integers the fused latent kernel
+    selects rows by) against every reference-held `select/*` vector of G2 (utils.mixture_component_selection run by
+    the reference on row-id tensors: B in {7, 8, 32, 56, 63, 64, 65, 256} x K in {1, 3, 7}) -- bit-exact."""
+    from mimic_amd.mmvae import kl_weights, mixture_row_starts
+    g = load("g2_edges")
+    keys = [k for k in g.files if k.startswith("select/")]
+    assert len(keys) == 24
+    for key in keys:
+        nrow, k = [int(v[1:]) for v in key.split("/")[1].split("_")]
+        starts = mixture_row_starts(nrow, k)
+        assert starts[0] == 0 and starts[-1] == nrow and len(starts) == k + 1
+        ids = np.concatenate([np.arange(i * nrow + a, i * nrow + b) for i, (a, b) in enumerate(zip(starts, starts[1:]))])
+        np.testing.assert_array_equal(ids, g[key], err_msg=key)
+        ranges = R.mixture_row_ranges(nrow, k)
+        assert [a for a, _ in ranges] + [nrow] == list(starts), key
+    assert [b - a for a, b in zip(mixture_row_starts(64, 7), mixture_row_starts(64, 7)[1:])] == [9] * 6 + [10]
+    assert abs(sum(kl_weights(7)) - 1.0) < 1e-6
+
+
 def test_g3_adam_trajectory_host(monkeypatch):
     torch_backend.install(monkeypatch)
     g = load("g3_traj")

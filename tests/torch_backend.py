@@ -171,6 +171,13 @@ def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False
     c = g.shape[-1]
     cdm = dm.reshape(-1, c).sum(0) if want_colsum_dm else None
     cds = ds.reshape(-1, c).sum(0) if want_colsum_ds else None
+    if small is not None:   # the HIP op's contract: the four small results land in the caller's pre-zeroed [4, C] slice
+        small[0].copy_(dgamma), small[1].copy_(dbeta)
+        dgamma, dbeta = small[0], small[1]
+        if cdm is not None:
+            cdm = small[2].copy_(cdm)
+        if cds is not None:
+            cds = small[3].copy_(cds)
     return dm.contiguous(), ds.contiguous(), dgamma, dbeta, cdm, cds
 
 
@@ -186,7 +193,12 @@ def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=
     dx = dx.contiguous()
     if next_s is not None:
         next_sums += bn_bwd_reduce(dx, next_s, next_bn)
-    return dx, sums[1].float(), sums[0].float(), cs
+    dgamma, dbeta = sums[1].float(), sums[0].float()
+    if small is not None:   # as the HIP op: results in the caller's pre-zeroed [3, C] slice
+        dgamma, dbeta = small[0].copy_(dgamma), small[1].copy_(dbeta)
+        if cs is not None:
+            cs = small[2].copy_(cs)
+    return dx, dgamma, dbeta, cs
 
 
 def bn_running_update(entries, momentum=0.1):
