@@ -44,6 +44,24 @@ __device__ __forceinline__ float mask_at(const mopoe_mask_ref& m, long row, int 
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// ---- bf16 storage (BASELINE configs #3, #5): activations / activation gradients / MFMA operands are bfloat16 in HBM,
+// every sum stays fp32 (statistics fp64).  A bf16 value is the upper half of the fp32 with the same value; rounding to
+// bf16 is round-to-nearest-even (the compiler's __bf16 conversion: v_cvt_pk_bf16_f32, NaN stays NaN).
+typedef unsigned short bf16_t;     // storage type at the C ABI (a plain 16-bit pattern)
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
+// the value a float has after a round trip through bf16 storage
+__device__ __forceinline__ float round_bf16(float f) { return bf16_lo(pack_bf16(f, 0.f)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

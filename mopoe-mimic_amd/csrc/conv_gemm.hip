@@ -22,23 +22,9 @@
 // LDS addresses are base + immediate (loop unrolled by two), and the mode flags are template specialisations.
 // The tile and the split of the reduction are launch-plan arguments (mopoe_conv_plan): the host mirror measures
 // the candidates per layer; the heuristics in launch_gather / mopoe_conv_wgrad are only the fallback.
-#include <stdlib.h>
-#include <algorithm>
-#include <initializer_list>
-
-#include <type_traits>
-
-#include "common.hpp"
+#include "gemm_common.hpp"
 
 namespace mopoe {
-
-// edge.hip: streaming kernels for the single-channel image-side layers
-bool edge_supported(const mopoe_conv_geom* g, int C, std::initializer_list<const void*> ptrs);
-int edge_expand(const float* scal, const float* W, float* out, const mopoe_conv_geom* g, int C, double* stats, hipStream_t st);
-int edge_wgrad(const float* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st);
-int edge_reduce(const float* x, const float* W, const float* bias, float* out, const mopoe_conv_geom* g, int C, hipStream_t st);
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x64 gather tile
 #ifndef TILE_N64_REMAINDER
@@ -62,7 +48,6 @@ constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x6
 #ifndef GEMM_BK_BIG
 #define GEMM_BK_BIG 16           // K-chunk of the 128x128 / 256x64 gather tiles
 #endif
-constexpr int MAX_BN_C = 1024;
 #ifndef GEMM_LDS_PAD
 #define GEMM_LDS_PAD 4
 #endif
@@ -91,10 +76,6 @@ struct GemmArgs {
   long rows_total;       // N*Hy*Wy
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// voffset past every buffer (operands are < 2 GiB, checked on the host): the hardware range check returns zeros.
-// 2^31 rather than ~0 so that voffset + soffset cannot wrap whichever of the two the range check includes.
-constexpr unsigned OOB = 0x80000000u;
 
 // 16-byte buffer load with hardware bounds check: no branch, no exec masking, zero for off >= bytes
 __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t srd, unsigned byte_off) {
@@ -122,33 +103,6 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
     if (nvalid > 3) v.w = p[3];
   }
   return v;
-}
-
-// ---- which taps a block multiplies, and from where --------------------------------------------------------------
-// form 0: every tap, source pixel = output pixel * stride - pad + tap.  form 1 (sub-pixel phase `phase` of the big
-// grid): only the taps congruent to the phase, source pixel = (output pixel + pad - tap) / stride, walked backwards.
-struct TapWalk {
-  int nty, ntx;          // taps of this phase along y / x
-  int ky0, kx0;          // first tap
-  int kstep_y, kstep_x;  // tap stride
-  int dsgn;              // +1: source moves forward with the tap, -1: backward
-  int cy, cx;            // source offset of the first tap (form 1)
-  int phy, phx;          // the phase (form 1)
-};
-__device__ __forceinline__ TapWalk tap_walk(const GemmArgs& a, int phase) {
-  TapWalk w;
-  w.cy = w.cx = w.phy = w.phx = 0;
-  if (a.form == 0) {
-    w.nty = a.kh; w.ntx = a.kw; w.ky0 = 0; w.kx0 = 0; w.kstep_y = 1; w.kstep_x = 1; w.dsgn = 1;
-  } else {
-    w.phy = phase / a.sw; w.phx = phase % a.sw;
-    const int ry = (w.phy + a.ph) % a.sh, rx = (w.phx + a.pw) % a.sw;
-    w.nty = ry < a.kh ? (a.kh - ry + a.sh - 1) / a.sh : 0;
-    w.ntx = rx < a.kw ? (a.kw - rx + a.sw - 1) / a.sw : 0;
-    w.ky0 = ry; w.kx0 = rx; w.kstep_y = a.sh; w.kstep_x = a.sw; w.dsgn = -1;
-    w.cy = (w.phy + a.ph - ry) / a.sh; w.cx = (w.phx + a.pw - rx) / a.sw;
-  }
-  return w;
 }
 
 // Tile configuration: BM x BN block tile, WGM x WGN waves (WGM*WGN == 4), each wave owns a
@@ -966,26 +920,6 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
 // =====================================================================================================
 // host-side launchers
 // =====================================================================================================
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-static int validate_geom(const mopoe_conv_geom* g) {
-  if (!g || g->N <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->Hb <= 0 || g->Wb <= 0 || g->Cin <= 0 || g->Cout <= 0 ||
-      g->kh <= 0 || g->kw <= 0 || g->sh <= 0 || g->sw <= 0 || g->ph < 0 || g->pw < 0) {
-    set_error("conv geometry: non-positive field");
-    return MOPOE_ERR_ARG;
-  }
-  if (g->Hb % g->sh != 0 || g->Wb % g->sw != 0) {
-    set_error("conv geometry: big grid (%d,%d) must be a multiple of the stride (%d,%d)", g->Hb, g->Wb, g->sh, g->sw);
-    return MOPOE_ERR_ARG;
-  }
-  // every small-grid pixel must map inside the padded big grid
-  if ((g->Hs - 1) * g->sh - g->ph + g->kh - 1 >= g->Hb + g->ph + g->sh || (g->Ws - 1) * g->sw - g->pw + g->kw - 1 >= g->Wb + g->pw + g->sw) {
-    set_error("conv geometry: small grid does not fit the big grid");
-    return MOPOE_ERR_ARG;
-  }
-  return 0;
-}
-
 // ---- split-K epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums ------
 // block = 64 columns x 4 row-lanes, grid-stride over rows (at most EPI_MAX_BLOCKS_Y blocks per column group so
 // that the column statistics leave as few same-address atomics as possible); the nsplit partials of one
@@ -1040,7 +974,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs a) 
   }
 }
 
-constexpr size_t WS_RECOMMENDED = 64u << 20;
 
 // dest_on_small: 1 -> form 0 (Y on the small grid), 0 -> form 1 (Y on the big grid)
 static int launch_gather(const float* X, const float* W, const float* bias, float* Y, const mopoe_conv_geom* g,

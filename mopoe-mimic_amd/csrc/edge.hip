@@ -17,9 +17,9 @@ struct EdgeGeom {
 constexpr int MAXT = 9;
 
 // thread owns VEC(4) fixed channels and walks small-grid pixels
-template <int NT, int KW>
+template <typename T, int NT, int KW>
 __global__ __launch_bounds__(EW_THREADS) void edge_expand_kernel(const float* __restrict__ scal, const float* __restrict__ W,
-                                                                float* __restrict__ out, const EdgeGeom g, double* stats) {
+                                                                T* __restrict__ out, const EdgeGeom g, double* stats) {
   const long rows = (long)g.N * g.Hs * g.Ws;
   const ColLayout L(g.C, 4);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(EW_THREADS) void edge_expand_kernel(const float* __
         const unsigned n = (unsigned)r / hw, rem = (unsigned)r - n * hw;
         const int qy = rem / g.Ws, qx = rem - qy * g.Ws;
         const float* src = scal + (long)n * g.Hb * g.Wb;
-        Vec<4> o;
+        VecT<T, 4> o;
         for (int e = 0; e < 4; ++e) o.v[e] = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(EW_THREADS) void edge_expand_kernel(const float* __
           if (by >= 0 && by < g.Hb && bx >= 0 && bx < g.Wb) sv = src[by * g.Wb + bx];
           for (int e = 0; e < 4; ++e) o.v[e] = fmaf(sv, w[t][e], o.v[e]);
         }
-        for (int e = 0; e < 4; ++e) { part[0][e] += o.v[e]; part[1][e] += o.v[e] * o.v[e]; }
+        for (int e = 0; e < 4; ++e) { o.v[e] = stored<T>(o.v[e]); part[0][e] += o.v[e]; part[1][e] += o.v[e] * o.v[e]; }
         o.st(out + r * g.C + (long)cv * 4);
       }
     }
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(EW_THREADS) void edge_expand_kernel(const float* __
   }
 }
 
-template <int NT, int KW>
-__global__ __launch_bounds__(EW_THREADS) void edge_wgrad_kernel(const float* __restrict__ vec, const float* __restrict__ scal,
+template <typename T, int NT, int KW>
+__global__ __launch_bounds__(EW_THREADS) void edge_wgrad_kernel(const T* __restrict__ vec, const float* __restrict__ scal,
                                                                float* __restrict__ dW, const EdgeGeom g) {
   const long rows = (long)g.N * g.Hs * g.Ws;
   const ColLayout L(g.C, 4);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(EW_THREADS) void edge_wgrad_kernel(const float* __r
         const unsigned n = (unsigned)r / hw, rem = (unsigned)r - n * hw;
         const int qy = rem / g.Ws, qx = rem - qy * g.Ws;
         const float* src = scal + (long)n * g.Hb * g.Wb;
-        const Vec<4> v = Vec<4>::ld(vec + r * g.C + (long)cv * 4);
+        const VecT<T, 4> v = VecT<T, 4>::ld(vec + r * g.C + (long)cv * 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int by = qy * g.sh - g.ph + t / KW, bx = qx * g.sw - g.pw + t % KW;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(EW_THREADS) void edge_wgrad_kernel(const float* __r
 }
 
 // head forward: 16 lanes per output pixel (4 channels each, C <= 64*... loops over channel groups), shuffle reduce
-template <int NT, int KW, int S>
-__global__ __launch_bounds__(256) void edge_reduce_kernel(const float* x, const float* W, const float* bias, float* out,
+template <typename T, int NT, int KW, int S>
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const T* x, const float* W, const float* bias, float* out,
                                                         const EdgeGeom g) {
   const long total = (long)g.N * g.Hb * g.Wb;
   const int sub = threadIdx.x & 15;                         // lane within the 16-lane group
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float* x, const 
       if (ny < 0 || nx < 0 || ny % S != 0 || nx % S != 0) continue;
       const int qy = ny / S, qx = nx / S;
       if (qy >= g.Hs || qx >= g.Ws) continue;
-      const float* xr = x + (((long)n * g.Hs + qy) * g.Ws + qx) * g.C;
+      const T* xr = x + (((long)n * g.Hs + qy) * g.Ws + qx) * g.C;
       const float* wr = W + (long)t * g.C;
       for (int c = sub * 4; c < g.C; c += 64) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const VecT<T, 4> xv = VecT<T, 4>::ld(xr + c);
         const float4 wv = *reinterpret_cast<const float4*>(wr + c);
-        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc);
-        acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        acc = fmaf(xv.v[0], wv.x, acc); acc = fmaf(xv.v[1], wv.y, acc);
+        acc = fmaf(xv.v[2], wv.z, acc); acc = fmaf(xv.v[3], wv.w, acc);
       }
     }
 #pragma unroll
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float* x, const 
 //   out[2a  ][2b+1] = x[a][b+1].W10 + x[a][b].W12
 //   out[2a+1][2b  ] = x[a+1][b].W01 + x[a][b].W21
 //   out[2a+1][2b+1] = x[a+1][b+1].W00 + x[a+1][b].W02 + x[a][b+1].W20 + x[a][b].W22
-template <bool C64>   // C64: C <= 64, one channel group per lane: the nine tap vectors stay in registers
-__global__ __launch_bounds__(256) void edge_reduce_quad_kernel(const float* x, const float* W, const float* bias, float* out,
+template <typename T, bool C64>   // C64: C <= 64, one channel group per lane: the nine tap vectors stay in registers
+__global__ __launch_bounds__(256) void edge_reduce_quad_kernel(const T* x, const float* W, const float* bias, float* out,
                                                              const EdgeGeom g) {
   const long total = (long)g.N * g.Hs * g.Ws;               // quads
   const int sub = threadIdx.x & 15;
@@ -157,17 +157,18 @@ __global__ __launch_bounds__(256) void edge_reduce_quad_kernel(const float* x, c
     const unsigned n = (unsigned)q / hws, rem = (unsigned)q - n * hws;
     const int a = rem / g.Ws, b = rem - a * g.Ws;
     const bool hy = a + 1 < g.Hs, hx = b + 1 < g.Ws;
-    const float* x00 = x + (((long)n * g.Hs + a) * g.Ws + b) * g.C;
+    const T* x00 = x + (((long)n * g.Hs + a) * g.Ws + b) * g.C;
     float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
     for (int c = sub * 4; c < g.C; c += 64) {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v00 = *reinterpret_cast<const float4*>(x00 + c);
-      const float4 v01 = hx ? *reinterpret_cast<const float4*>(x00 + g.C + c) : z;
-      const float4 v10 = hy ? *reinterpret_cast<const float4*>(x00 + (long)g.Ws * g.C + c) : z;
-      const float4 v11 = (hx && hy) ? *reinterpret_cast<const float4*>(x00 + (long)(g.Ws + 1) * g.C + c) : z;
-      auto dot = [&](const float4& u, int tap) {
+      VecT<T, 4> z;
+      z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
+      const VecT<T, 4> v00 = VecT<T, 4>::ld(x00 + c);
+      const VecT<T, 4> v01 = hx ? VecT<T, 4>::ld(x00 + g.C + c) : z;
+      const VecT<T, 4> v10 = hy ? VecT<T, 4>::ld(x00 + (long)g.Ws * g.C + c) : z;
+      const VecT<T, 4> v11 = (hx && hy) ? VecT<T, 4>::ld(x00 + (long)(g.Ws + 1) * g.C + c) : z;
+      auto dot = [&](const VecT<T, 4>& u, int tap) {
         const float4 w = C64 ? wreg[tap] : *reinterpret_cast<const float4*>(W + (long)tap * g.C + c);
-        return fmaf(u.x, w.x, fmaf(u.y, w.y, fmaf(u.z, w.z, u.w * w.w)));
+        return fmaf(u.v[0], w.x, fmaf(u.v[1], w.y, fmaf(u.v[2], w.z, u.v[3] * w.w)));
       };
       o00 += dot(v00, 4);
       o01 += dot(v01, 3) + dot(v00, 5);
@@ -191,43 +192,55 @@ static EdgeGeom edge_geom(const mopoe_conv_geom* g, int C) {
   return EdgeGeom{g->N, g->Hs, g->Ws, g->Hb, g->Wb, C, g->kh, g->kw, g->sh, g->sw, g->ph, g->pw};
 }
 
-// ---- entry points used by conv_gemm.hip's dispatch ------------------------------------------------------------
+// ---- entry points used by the conv dispatchers (conv_gemm.hip: T = float, conv_gemm_bf16.hip: T = bf16_t) ---------
+// The wide ([pixels][C]) tensor has storage type T; the single-channel image side, the taps W[9][C] and the tap
+// gradients stay fp32 in both cases.
 bool edge_supported(const mopoe_conv_geom* g, int C, std::initializer_list<const void*> ptrs) {
   return g->kh == 3 && g->kw == 3 && g->sh == 2 && g->sw == 2 && C % 4 == 0 && C >= 4 && vec_ok(C, ptrs);
 }
 
-int edge_expand(const float* scal, const float* W, float* out, const mopoe_conv_geom* g, int C, double* stats,
+template <typename T>
+int edge_expand(const float* scal, const float* W, T* out, const mopoe_conv_geom* g, int C, double* stats,
                 hipStream_t st) {
   const EdgeGeom eg = edge_geom(g, C);
   const long rows = (long)g->N * g->Hs * g->Ws;
-  hipLaunchKernelGGL((edge_expand_kernel<9, 3>), dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, scal, W, out, eg, stats);
+  hipLaunchKernelGGL((edge_expand_kernel<T, 9, 3>), dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, scal, W, out, eg, stats);
   return check_launch("edge_expand");
 }
 
-int edge_wgrad(const float* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st) {
+template <typename T>
+int edge_wgrad(const T* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st) {
   const EdgeGeom eg = edge_geom(g, C);
   const long rows = (long)g->N * g->Hs * g->Ws;
   if (hipMemsetAsync(dW, 0, sizeof(float) * 9 * C, st) != hipSuccess) { set_error("edge_wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
-  hipLaunchKernelGGL((edge_wgrad_kernel<9, 3>), dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, vec, scal, dW, eg);
+  hipLaunchKernelGGL((edge_wgrad_kernel<T, 9, 3>), dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, vec, scal, dW, eg);
   return check_launch("edge_wgrad");
 }
 
-int edge_reduce(const float* x, const float* W, const float* bias, float* out, const mopoe_conv_geom* g, int C,
+template <typename T>
+int edge_reduce(const T* x, const float* W, const float* bias, float* out, const mopoe_conv_geom* g, int C,
                 hipStream_t st) {
   const EdgeGeom eg = edge_geom(g, C);
   if (g->ph == 1 && g->pw == 1 && g->Hb == 2 * g->Hs && g->Wb == 2 * g->Ws && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
     const long quads = (long)g->N * g->Hs * g->Ws;
     long qb = (quads * 16 + 255) / 256;
     if (qb > 4096) qb = 4096;
-    if (C <= 64) hipLaunchKernelGGL(edge_reduce_quad_kernel<true>, dim3((unsigned)qb), dim3(256), 0, st, x, W, bias, out, eg);
-    else hipLaunchKernelGGL(edge_reduce_quad_kernel<false>, dim3((unsigned)qb), dim3(256), 0, st, x, W, bias, out, eg);
+    if (C <= 64) hipLaunchKernelGGL((edge_reduce_quad_kernel<T, true>), dim3((unsigned)qb), dim3(256), 0, st, x, W, bias, out, eg);
+    else hipLaunchKernelGGL((edge_reduce_quad_kernel<T, false>), dim3((unsigned)qb), dim3(256), 0, st, x, W, bias, out, eg);
     return check_launch("edge_reduce_quad");
   }
   const long total = (long)g->N * g->Hb * g->Wb;
   long blocks = (total * 16 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL((edge_reduce_kernel<9, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, x, W, bias, out, eg);
+  hipLaunchKernelGGL((edge_reduce_kernel<T, 9, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, x, W, bias, out, eg);
   return check_launch("edge_reduce");
 }
+
+template int edge_expand<float>(const float*, const float*, float*, const mopoe_conv_geom*, int, double*, hipStream_t);
+template int edge_expand<bf16_t>(const float*, const float*, bf16_t*, const mopoe_conv_geom*, int, double*, hipStream_t);
+template int edge_wgrad<float>(const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
+template int edge_wgrad<bf16_t>(const bf16_t*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
+template int edge_reduce<float>(const float*, const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
+template int edge_reduce<bf16_t>(const bf16_t*, const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
 
 }  // namespace mopoe

@@ -3,13 +3,15 @@
 // registers) and walks rows with a grid stride; loads/stores are 16 bytes per lane when C % 4 == 0.
 // Column reductions (BN statistics, BN-backward sums, bias gradients) are reduced per block through
 // LDS and leave the block as one atomic per column.
+#include <type_traits>
+
 #include "ew_common.hpp"
 
 namespace mopoe {
 
 // ---- out = a*bn(s) + b*m  (+ stats of out) -----------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const float* s, const float* m, float* out, long rows,
+template <typename T, int VEC>
+__global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* s, const T* m, T* out, long rows,
                                                                  int C, mopoe_bn_ref bn, float a, float b, double* stats) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
@@ -24,10 +26,10 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const float* 
     if (active) {
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
         const long off = r * C + (long)cv * VEC;
-        const Vec<VEC> vs = Vec<VEC>::ld(s + off), vm = Vec<VEC>::ld(m + off);
-        Vec<VEC> o;
+        const VecT<T, VEC> vs = VecT<T, VEC>::ld(s + off), vm = VecT<T, VEC>::ld(m + off);
+        VecT<T, VEC> o;
         for (int e = 0; e < VEC; ++e) {
-          o.v[e] = fmaf(vs.v[e], sc[e], sh[e]) + b * vm.v[e];
+          o.v[e] = stored<T>(fmaf(vs.v[e], sc[e], sh[e]) + b * vm.v[e]);
           part[0][e] += o.v[e];
           part[1][e] += o.v[e] * o.v[e];
         }
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const float* 
 }
 
 // ---- sums += {sum g, sum g*shat} -----------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float* g, const float* s, long rows, int C,
+template <typename T, int VEC>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* g, const T* s, long rows, int C,
                                                                  mopoe_bn_ref bn, double* sums) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float* 
     if (active) {
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
         const long off = r * C + (long)cv * VEC;
-        const Vec<VEC> vg = Vec<VEC>::ld(g + off), vs = Vec<VEC>::ld(s + off);
+        const VecT<T, VEC> vg = VecT<T, VEC>::ld(g + off), vs = VecT<T, VEC>::ld(s + off);
         for (int e = 0; e < VEC; ++e) {
           part[0][e] += vg.v[e];
           part[1][e] += vg.v[e] * ((vs.v[e] - mean[e]) * rstd[e]);
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float* 
 }
 
 // ---- dm = b*g*mask ; ds = a*BNbwd(g; s) ---------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* g, const float* s, float* dm, float* ds,
+template <typename T, int VEC>
+__global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* g, const T* s, T* dm, T* ds,
                                                                  long rows, int C, mopoe_bn_ref bn, const double* sums,
                                                                  mopoe_mask_ref mask, float a, float b, float* dgamma,
                                                                  float* dbeta, float* colsum_dm, float* colsum_ds) {
@@ -99,16 +101,16 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* 
     if (active) {
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
         const long off = r * C + (long)cv * VEC;
-        const Vec<VEC> vg = Vec<VEC>::ld(g + off), vs = Vec<VEC>::ld(s + off);
-        Vec<VEC> om, os;
+        const VecT<T, VEC> vg = VecT<T, VEC>::ld(g + off), vs = VecT<T, VEC>::ld(s + off);
+        VecT<T, VEC> om, os;
         const float* mrow = nullptr;
         if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
         else if (mask.kind == 2) mrow = mask.mask + r * C;
         for (int e = 0; e < VEC; ++e) {
           const float mk = mrow ? mrow[cv * VEC + e] : 1.f;
-          om.v[e] = b * vg.v[e] * mk;
+          om.v[e] = stored<T>(b * vg.v[e] * mk);
           const float shat = (vs.v[e] - mean[e]) * rstd[e];
-          os.v[e] = gr[e] * (vg.v[e] - k1[e] - shat * k2[e]);
+          os.v[e] = stored<T>(gr[e] * (vg.v[e] - k1[e] - shat * k2[e]));
           part[0][e] += om.v[e];
           part[1][e] += os.v[e];
         }
@@ -128,11 +130,11 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const float* 
 // NEXT: dx is the gradient entering the previous residual block, whose first backward step is the pair of column
 // reductions {sum dx, sum dx * shat} over its shortcut output s (bn_bwd_reduce).  Producing them here saves that
 // kernel and its re-read of dx.
-template <int VEC, bool NEXT>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* dy, const float* x, const float* add,
-                                                                float* dx, long rows, int C, mopoe_bn_ref bn,
+template <typename T, int VEC, bool NEXT>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* dy, const T* x, const T* add,
+                                                                T* dx, long rows, int C, mopoe_bn_ref bn,
                                                                 const double* sums, mopoe_mask_ref mask, float* dgamma,
-                                                                float* dbeta, float* colsum_dx, const float* next_s,
+                                                                float* dbeta, float* colsum_dx, const T* next_s,
                                                                 mopoe_bn_ref next_bn, double* next_sums) {
   constexpr int NACC = NEXT ? 3 : 1;
   const ColLayout L(C, VEC);
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
     if (active) {
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
         const long off = r * C + (long)cv * VEC;
-        const Vec<VEC> vd = Vec<VEC>::ld(dy + off), vx = Vec<VEC>::ld(x + off);
-        Vec<VEC> va, vs, o;
-        if (add) va = Vec<VEC>::ld(add + off);
-        if (NEXT) vs = Vec<VEC>::ld(next_s + off);
+        const VecT<T, VEC> vd = VecT<T, VEC>::ld(dy + off), vx = VecT<T, VEC>::ld(x + off);
+        VecT<T, VEC> va, vs, o;
+        if (add) va = VecT<T, VEC>::ld(add + off);
+        if (NEXT) vs = VecT<T, VEC>::ld(next_s + off);
         const float* mrow = nullptr;
         if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
         else if (mask.kind == 2) mrow = mask.mask + r * C;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
           float v = gr[e] * (vd.v[e] - k1[e] - xhat * k2[e]);
           if (mrow) v *= mrow[cv * VEC + e];
           if (add) v += va.v[e];
+          v = stored<T>(v);
           o.v[e] = v;
           part[0][e] += v;
           if constexpr (NEXT) { part[1][e] += v; part[2][e] += v * ((vs.v[e] - nmean[e]) * nrstd[e]); }
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const float* d
 }
 
 // ---- column sums -----------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* x, float* out, long rows, int C) {
+template <typename T, int VEC>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const T* x, float* out, long rows, int C) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* x, floa
     for (int e = 0; e < VEC; ++e) part[0][e] = 0.f;
     if (active) {
       for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const Vec<VEC> v = Vec<VEC>::ld(x + r * C + (long)cv * VEC);
+        const VecT<T, VEC> v = VecT<T, VEC>::ld(x + r * C + (long)cv * VEC);
         for (int e = 0; e < VEC; ++e) part[0][e] += v.v[e];
       }
     }
@@ -238,47 +241,73 @@ using namespace mopoe;
 #define EW_ARGCHECK(cond, msg) \
   if (!(cond)) { set_error(msg); return MOPOE_ERR_ARG; }
 
-extern "C" int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
-                                   const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream) {
+// ---- typed launchers: T = float (VEC 4, or 1 for ragged channel counts) or bf16_t (VEC 8; C % 8 == 0 required) -------
+template <typename T> struct EwVec { static constexpr int wide = 4; };
+template <> struct EwVec<bf16_t> { static constexpr int wide = 8; };
+
+template <typename T>
+static bool ew_wide_ok(int C, std::initializer_list<const void*> ptrs, const char* what, int* rc) {
+  const bool ok = vec_ok(C, ptrs, EwVec<T>::wide);
+  *rc = MOPOE_OK;
+  if (!ok && std::is_same<T, bf16_t>::value) {
+    set_error("%s (bf16): needs C %% 8 == 0 (C = %d) and 16-byte aligned tensors", what, C);
+    *rc = MOPOE_ERR_ARG;
+  }
+  return ok;
+}
+
+template <typename T>
+static int block_out_fwd_t(const T* s, const T* m, T* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s, float a,
+                           float b, double* out_stats, void* stream) {
   EW_ARGCHECK(s && m && out && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0, "block_out_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(C, {s, m, out}))
-    hipLaunchKernelGGL(block_out_fwd_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
-  else
-    hipLaunchKernelGGL(block_out_fwd_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+  if (ew_wide_ok<T>(C, {s, m, out}, "block_out_fwd", &rc))
+    hipLaunchKernelGGL((block_out_fwd_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+  else if constexpr (std::is_same<T, float>::value)
+    hipLaunchKernelGGL((block_out_fwd_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+  else return rc;
   return check_launch("block_out_fwd");
 }
 
-extern "C" int mopoe_bn_bwd_reduce(const float* g, const float* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,
-                                   double* sums, void* stream) {
+template <typename T>
+static int bn_bwd_reduce_t(const T* g, const T* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s, double* sums,
+                           void* stream) {
   EW_ARGCHECK(g && s && sums && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0, "bn_bwd_reduce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(C, {g, s}))
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+  if (ew_wide_ok<T>(C, {g, s}, "bn_bwd_reduce", &rc))
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+  else if constexpr (std::is_same<T, float>::value)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+  else return rc;
   return check_launch("bn_bwd_reduce");
 }
 
-extern "C" int mopoe_block_out_bwd(const float* g, const float* s, float* dm, float* ds, int64_t rows, int32_t C,
-                                   const mopoe_bn_ref* bn_s, const double* sums, const mopoe_mask_ref* mask, float a,
-                                   float b, float* dgamma, float* dbeta, float* colsum_dm, float* colsum_ds,
-                                   void* stream) {
+template <typename T>
+static int block_out_bwd_t(const T* g, const T* s, T* dm, T* ds, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,
+                           const double* sums, const mopoe_mask_ref* mask, float a, float b, float* dgamma, float* dbeta,
+                           float* colsum_dm, float* colsum_ds, void* stream) {
   EW_ARGCHECK(g && s && dm && ds && sums && dgamma && dbeta && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0,
               "block_out_bwd: bad arguments");
   mopoe_mask_ref mk = mask ? *mask : mopoe_mask_ref{nullptr, 0, 1};
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(C, {g, s, dm, ds}))
-    hipLaunchKernelGGL(block_out_bwd_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
-  else
-    hipLaunchKernelGGL(block_out_bwd_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+  if (ew_wide_ok<T>(C, {g, s, dm, ds}, "block_out_bwd", &rc))
+    hipLaunchKernelGGL((block_out_bwd_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+  else if constexpr (std::is_same<T, float>::value)
+    hipLaunchKernelGGL((block_out_bwd_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+  else return rc;
   return check_launch("block_out_bwd");
 }
 
-extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows, int32_t C,
-                                  const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask, float* dgamma,
-                                  float* dbeta, float* colsum_dx, const float* next_s, const mopoe_bn_ref* next_bn,
-                                  double* next_sums, void* stream) {
+template <typename T>
+static int bn_bwd_apply_t(const T* dy, const T* x, const T* add, T* dx, int64_t rows, int32_t C, const mopoe_bn_ref* bn,
+                          const double* sums, const mopoe_mask_ref* mask, float* dgamma, float* dbeta, float* colsum_dx,
+                          const T* next_s, const mopoe_bn_ref* next_bn, double* next_sums, void* stream) {
   EW_ARGCHECK(dy && x && dx && sums && dgamma && dbeta && bn && bn->mode != 0 && bn->C == C && rows > 0,
               "bn_bwd_apply: bad arguments");
   const bool next = next_s != nullptr;
@@ -287,13 +316,76 @@ extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* 
   mopoe_mask_ref mk = mask ? *mask : mopoe_mask_ref{nullptr, 0, 1};
   const mopoe_bn_ref nb = next ? *next_bn : mopoe_bn_ref{};
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = vec_ok(C, {dy, x, add, dx, next_s});
-  const dim3 grid(ew_grid(rows, C, vec ? 4 : 1)), blk(EW_THREADS);
-#define MOPOE_APPLY(V_, N_) hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, N_>), grid, blk, 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx, next_s, nb, next_sums)
-  if (vec) { if (next) MOPOE_APPLY(4, true); else MOPOE_APPLY(4, false); }
-  else { if (next) MOPOE_APPLY(1, true); else MOPOE_APPLY(1, false); }
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+  const bool vec = ew_wide_ok<T>(C, {dy, x, add, dx, next_s}, "bn_bwd_apply", &rc);
+  if (!vec && !std::is_same<T, float>::value) return rc;
+  const dim3 grid(ew_grid(rows, C, vec ? W : 1)), blk(EW_THREADS);
+#define MOPOE_APPLY(V_, N_) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, N_>), grid, blk, 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx, next_s, nb, next_sums)
+  if (vec) { if (next) MOPOE_APPLY(W, true); else MOPOE_APPLY(W, false); }
+  else if constexpr (std::is_same<T, float>::value) { if (next) MOPOE_APPLY(1, true); else MOPOE_APPLY(1, false); }
 #undef MOPOE_APPLY
   return check_launch("bn_bwd_apply");
+}
+
+template <typename T>
+static int colsum_t(const T* x, float* out, int64_t rows, int32_t C, void* stream) {
+  EW_ARGCHECK(x && out && rows > 0 && C > 0, "colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+  if (ew_wide_ok<T>(C, {x}, "colsum", &rc))
+    hipLaunchKernelGGL((colsum_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+  else if constexpr (std::is_same<T, float>::value)
+    hipLaunchKernelGGL((colsum_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+  else return rc;
+  return check_launch("colsum");
+}
+
+extern "C" int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
+                                   const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream) {
+  return block_out_fwd_t<float>(s, m, out, rows, C, bn_s, a, b, out_stats, stream);
+}
+extern "C" int mopoe_block_out_fwd_bf16(const uint16_t* s, const uint16_t* m, uint16_t* out, int64_t rows, int32_t C,
+                                        const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream) {
+  return block_out_fwd_t<bf16_t>(s, m, out, rows, C, bn_s, a, b, out_stats, stream);
+}
+
+extern "C" int mopoe_bn_bwd_reduce(const float* g, const float* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,
+                                   double* sums, void* stream) {
+  return bn_bwd_reduce_t<float>(g, s, rows, C, bn_s, sums, stream);
+}
+extern "C" int mopoe_bn_bwd_reduce_bf16(const uint16_t* g, const uint16_t* s, int64_t rows, int32_t C,
+                                        const mopoe_bn_ref* bn_s, double* sums, void* stream) {
+  return bn_bwd_reduce_t<bf16_t>(g, s, rows, C, bn_s, sums, stream);
+}
+
+extern "C" int mopoe_block_out_bwd(const float* g, const float* s, float* dm, float* ds, int64_t rows, int32_t C,
+                                   const mopoe_bn_ref* bn_s, const double* sums, const mopoe_mask_ref* mask, float a,
+                                   float b, float* dgamma, float* dbeta, float* colsum_dm, float* colsum_ds,
+                                   void* stream) {
+  return block_out_bwd_t<float>(g, s, dm, ds, rows, C, bn_s, sums, mask, a, b, dgamma, dbeta, colsum_dm, colsum_ds, stream);
+}
+extern "C" int mopoe_block_out_bwd_bf16(const uint16_t* g, const uint16_t* s, uint16_t* dm, uint16_t* ds, int64_t rows,
+                                        int32_t C, const mopoe_bn_ref* bn_s, const double* sums,
+                                        const mopoe_mask_ref* mask, float a, float b, float* dgamma, float* dbeta,
+                                        float* colsum_dm, float* colsum_ds, void* stream) {
+  return block_out_bwd_t<bf16_t>(g, s, dm, ds, rows, C, bn_s, sums, mask, a, b, dgamma, dbeta, colsum_dm, colsum_ds, stream);
+}
+
+extern "C" int mopoe_bn_bwd_apply(const float* dy, const float* x, const float* add, float* dx, int64_t rows, int32_t C,
+                                  const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask, float* dgamma,
+                                  float* dbeta, float* colsum_dx, const float* next_s, const mopoe_bn_ref* next_bn,
+                                  double* next_sums, void* stream) {
+  return bn_bwd_apply_t<float>(dy, x, add, dx, rows, C, bn, sums, mask, dgamma, dbeta, colsum_dx, next_s, next_bn, next_sums, stream);
+}
+extern "C" int mopoe_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* add, uint16_t* dx,
+                                       int64_t rows, int32_t C, const mopoe_bn_ref* bn, const double* sums,
+                                       const mopoe_mask_ref* mask, float* dgamma, float* dbeta, float* colsum_dx,
+                                       const uint16_t* next_s, const mopoe_bn_ref* next_bn, double* next_sums,
+                                       void* stream) {
+  return bn_bwd_apply_t<bf16_t>(dy, x, add, dx, rows, C, bn, sums, mask, dgamma, dbeta, colsum_dx, next_s, next_bn, next_sums, stream);
 }
 
 extern "C" int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_t n, float momentum, void* stream) {
@@ -313,12 +405,8 @@ extern "C" int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_
 }
 
 extern "C" int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream) {
-  EW_ARGCHECK(x && out && rows > 0 && C > 0, "colsum: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
-  if (vec_ok(C, {x}))
-    hipLaunchKernelGGL(colsum_kernel<4>, dim3(ew_grid(rows, C, 4)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
-  else
-    hipLaunchKernelGGL(colsum_kernel<1>, dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
-  return check_launch("colsum");
+  return colsum_t<float>(x, out, rows, C, stream);
+}
+extern "C" int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, void* stream) {
+  return colsum_t<bf16_t>(x, out, rows, C, stream);
 }

@@ -8,23 +8,53 @@ namespace mopoe {
 constexpr int EW_THREADS = 256;
 constexpr int EW_MAX_BLOCKS = 512;
 
-template <int VEC>
-struct Vec;
+// VEC consecutive channels of a row as floats, whatever the storage type T (float or bf16_t) is
+template <typename T, int VEC>
+struct VecT;
 template <>
-struct Vec<4> {
+struct VecT<float, 4> {
   float v[4];
-  __device__ static Vec ld(const float* p) {
+  __device__ static VecT ld(const float* p) {
     const float4 t = *reinterpret_cast<const float4*>(p);
-    Vec r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+    VecT r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
   }
   __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <>
-struct Vec<1> {
+struct VecT<float, 1> {
   float v[1];
-  __device__ static Vec ld(const float* p) { Vec r; r.v[0] = *p; return r; }
+  __device__ static VecT ld(const float* p) { VecT r; r.v[0] = *p; return r; }
   __device__ void st(float* p) const { *p = v[0]; }
 };
+template <>
+struct VecT<bf16_t, 8> {   // 16 bytes per lane
+  float v[8];
+  __device__ static VecT ld(const bf16_t* p) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    VecT r;
+    r.v[0] = bf16_lo(t.x); r.v[1] = bf16_hi(t.x); r.v[2] = bf16_lo(t.y); r.v[3] = bf16_hi(t.y);
+    r.v[4] = bf16_lo(t.z); r.v[5] = bf16_hi(t.z); r.v[6] = bf16_lo(t.w); r.v[7] = bf16_hi(t.w);
+    return r;
+  }
+  __device__ void st(bf16_t* p) const {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  }
+};
+template <>
+struct VecT<bf16_t, 4> {   // 8 bytes per lane (edge kernels: 16 lanes x 4 channels per pixel)
+  float v[4];
+  __device__ static VecT ld(const bf16_t* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    VecT r; r.v[0] = bf16_lo(t.x); r.v[1] = bf16_hi(t.x); r.v[2] = bf16_lo(t.y); r.v[3] = bf16_hi(t.y); return r;
+  }
+  __device__ void st(bf16_t* p) const { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])); }
+};
+template <int VEC>
+using Vec = VecT<float, VEC>;
+// what a value reads back as after it has been stored (statistics are taken over the STORED tensor)
+template <typename T> __device__ __forceinline__ float stored(float f);
+template <> __device__ __forceinline__ float stored<float>(float f) { return f; }
+template <> __device__ __forceinline__ float stored<bf16_t>(float f) { return round_bf16(f); }
 
 // column layout of a block: `cols` vector-columns per pass, `rpp` rows per pass
 struct ColLayout {
@@ -83,8 +113,8 @@ static inline int ew_grid(long rows, int C, int VEC) {
   return (int)blocks;
 }
 
-static inline bool vec_ok(int C, std::initializer_list<const void*> ptrs) {
-  if (C % 4 != 0) return false;
+static inline bool vec_ok(int C, std::initializer_list<const void*> ptrs, int vec = 4) {
+  if (C % vec != 0) return false;
   for (const void* p : ptrs)
     if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
   return true;
