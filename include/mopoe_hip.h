@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 7
+#define MOPOE_ABI_VERSION 8
 
 /* error codes */
 #define MOPOE_OK 0
@@ -245,6 +245,60 @@ int mopoe_embedding_fwd(const float* ids, const float* table, float* out, int64_
 int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int64_t rows, int32_t V,
                         int32_t D, int32_t padding_idx, void* stream);
 
+
+/* ==== bf16 storage family (BASELINE configs #3, #5) ===================================================================
+ * Same operations with activations, activation gradients and the MFMA operands stored as bfloat16 (uint16_t bit
+ * patterns at this ABI), fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Still fp32 / fp64: bias, dropout masks, BN
+ * affine parameters and statistics (taken over the STORED, i.e. rounded, values), BN-backward sums, weight gradients
+ * (mopoe_conv_wgrad_bf16 writes fp32: they feed Adam on the fp32 master weights), the latent kernel and the
+ * likelihoods.  Weights: a bf16 copy of the packed fp32 master tensor Wp[kh*kw][Cin][Cout] -- one layout serves
+ * forward (transposed LDS reads), input gradient and the weight gradient's destination.
+ * Requirements: K channels % 32 == 0, N channels % 8 == 0 (glue kernels: C % 8 == 0), 16-byte aligned tensors < 2 GiB;
+ * anything else returns MOPOE_ERR_ARG (there is no scalar fallback in this family).
+ * y_is_f32 / dx_is_f32 != 0: the result is written as fp32 (latent projections, gradients entering the latent kernel).
+ * Launch plans: tile -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 (8 waves) | 4 = 128x64; split as above.
+ * Replaces the same reference call sites as the fp32 family (the reference itself has no bf16 mode: BASELINE.json
+ * configs #3/#5 define it; SURVEY section 8c sets the tolerance, rtol 2e-2 against the fp32 reference arithmetic). */
+int mopoe_conv_fwd_bf16(const uint16_t* x, const uint16_t* wp, const float* bias, void* y, int32_t y_is_f32,
+                        const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
+                        double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int mopoe_conv_dgrad_bf16(const uint16_t* dy, const uint16_t* wp, void* dx, int32_t dx_is_f32, const mopoe_conv_geom* g,
+                          const mopoe_bn_ref* relu_bn, const uint16_t* xin, double* bwd_sums,
+                          const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes, void* stream);
+int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dwp, const mopoe_conv_geom* g,
+                          const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, const mopoe_conv_plan* plan, void* stream);
+/* image-side edge layers (FeatureExtractorImg.py:29-34 stem, DataGeneratorImg.py:84-90 head): the single-channel image,
+ * the 3x3 taps w[9][C] and their gradients stay fp32, the wide [pixels][C] tensor is bf16.
+ *   expand: out[p][c] = sum_tap scal[gather(p, tap)] * w[tap][c]     stem forward; head input gradient
+ *   wgrad:  dw[tap][c] = sum_p vec[p][c] * scal[gather(p, tap)]      stem / head weight gradient
+ *   reduce: out[q] = bias + sum_tap sum_c x[p(q, tap)][c] * w[tap][c]  head forward */
+int mopoe_edge_expand_bf16(const float* scal, const float* w, uint16_t* out, const mopoe_conv_geom* g, int32_t C,
+                           double* stats, void* stream);
+int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, const mopoe_conv_geom* g, int32_t C,
+                          void* stream);
+int mopoe_edge_reduce_bf16(const uint16_t* x, const float* w, const float* bias, float* out, const mopoe_conv_geom* g,
+                           int32_t C, void* stream);
+/* residual-block glue on bf16 tensors (same arithmetic in fp32 registers; results rounded once when stored) */
+int mopoe_block_out_fwd_bf16(const uint16_t* s, const uint16_t* m, uint16_t* out, int64_t rows, int32_t C,
+                             const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream);
+int mopoe_bn_bwd_reduce_bf16(const uint16_t* g, const uint16_t* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,
+                             double* sums, void* stream);
+int mopoe_block_out_bwd_bf16(const uint16_t* g, const uint16_t* s, uint16_t* dm, uint16_t* ds, int64_t rows, int32_t C,
+                             const mopoe_bn_ref* bn_s, const double* sums, const mopoe_mask_ref* mask, float a, float b,
+                             float* dgamma, float* dbeta, float* colsum_dm, float* colsum_ds, void* stream);
+int mopoe_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* add, uint16_t* dx, int64_t rows,
+                            int32_t C, const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask,
+                            float* dgamma, float* dbeta, float* colsum_dx, const uint16_t* next_s,
+                            const mopoe_bn_ref* next_bn, double* next_sums, void* stream);
+int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, void* stream);
+/* embedding with a bf16 activation: out[r, :] = bf16(table[ids[r], :]) (fp32 table); backward scatter-adds the bf16
+ * gradient rows into the fp32 dtable (overwritten), skipping padding_idx */
+int mopoe_embedding_fwd_bf16(const float* ids, const float* table, uint16_t* out, int64_t rows, int32_t V, int32_t D,
+                             void* stream);
+int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtable, int64_t rows, int32_t V, int32_t D,
+                             int32_t padding_idx, void* stream);
+
 /* ---- profiling support for bench.py ------------------------------------------------------------------
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
  * stream.  mopoe_prof_collect synchronises those events and fills, per kernel instantiation (arrays of
@@ -255,8 +309,10 @@ int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int6
  *   32..34 gather_gemm_kernel, scalar path: 128x128, 256x64, 64x64
  *   36..41 wgrad_gemm_kernel, vector path: (128x128 ? 0 : 3) + spec (0 run-time modes, 1 plain, 2 BN+ReLU on x)
  *   42..43 wgrad_gemm_kernel, scalar path: 128x128, 64x64
- *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec */
-#define MOPOE_PROF_KINDS 60
+ *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec
+ *   60..74 gather_gemm_bf16_kernel: tile * 3 + (spec - 1)   (tiles 0..4 of the bf16 family)
+ *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
+#define MOPOE_PROF_KINDS 80
 int mopoe_prof_enable(int32_t on);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
 

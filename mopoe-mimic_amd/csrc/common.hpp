@@ -82,7 +82,10 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 //   wgrad,  vector path:  36 + (128x128 ? 0 : 3) + spec   (spec 0..2)              kinds 36..41
 //   wgrad,  scalar path:  42 + (128x128 ? 0 : 1)                                   kinds 42..43
 //   direct (LDS-free) gather: 44 + (tile - 8) * 4 + spec                           kinds 44..59
-enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44, PROF_NKINDS = MOPOE_PROF_KINDS };
+//   bf16 gather:          60 + tile * 3 + (spec - 1)     (tile 0..4, spec 1..3)    kinds 60..74
+//   bf16 wgrad:           75 + (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)          kinds 75..78
+enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44,
+       PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {
   hipStream_t stream;
   int slot;

@@ -1,0 +1,824 @@
+// Implicit-GEMM convolution family on bf16 MFMA (v_mfma_f32_32x32x16_bf16) for gfx950: bf16 operands from HBM, fp32
+// accumulation, bf16 (or fp32) results -- BASELINE configs #3 and #5.
+//
+// Same problem statement as conv_gemm.hip (activations = channels-last row matrices [pixels][C], weights packed
+// Wp[tap][Cin][Cout], gather forms 0 / 1, weight gradient), different machine mapping: one bf16 MFMA consumes, per
+// lane, EIGHT consecutive K elements of its row / column (A[row = lane % 32][k = 8 (lane / 32) + j], B[k][col]),
+// i.e. 16 bytes, so
+//   * an operand whose K runs along memory (activations: K = channels; weights of the input gradient: K = Cout)
+//     is staged as [row][k] LDS rows of 80 bytes (64 + 16 pad: the 16 rows a ds_read_b128 lane group touches then
+//     sit in 16 different 16-byte bank slots) and read with one ds_read_b128 per fragment;
+//   * an operand whose K is the STRIDED index (forward weights Wp[k = ci][n = co]; both operands of the weight
+//     gradient, where K = pixels) is staged exactly as it lies in memory, [k][n] rows, and read with the hardware
+//     transpose ds_read_b64_tr_b16 (two per fragment); the row stride is 64 bytes more than a multiple of 256 so the four
+//     k-rows of one transposed read fall into four different quarters of the bank row.
+// Nothing is re-laid out in HBM: the bf16 copy of a weight tensor serves forward, input gradient and (as the
+// destination layout) the weight gradient.
+// Rounding points (the test oracle has a bf16 mode that rounds at the same places): operands after
+// BN+ReLU, and every stored result; bias, dropout mask, statistics and the BN-backward sums are fp32 / fp64 as in the
+// fp32 family, and statistics are taken over the STORED (rounded) values.
+// Requirements (all BASELINE configurations meet them; anything else is rejected with MOPOE_ERR_ARG, there is no
+// scalar fallback): K channels a multiple of 32, N channels a multiple of 8, 16-byte aligned tensors < 2 GiB.
+#include "gemm_common.hpp"
+
+namespace mopoe {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int BKH = 32;   // K chunk in bf16 elements (two 16-deep MFMA steps); Ck % BKH == 0 is required
+
+struct GemmArgsH {
+  const bf16_t* X;       // gathered operand [rows_x][ldx]
+  const bf16_t* W;       // Wp[tap][Cin_w][Cout_w]
+  void* Y;               // bf16_t or float [rows_total][ldy]
+  const float* bias;
+  int N, Hx, Wx, Hy, Wy, Ck, Cn, Cin_w, Cout_w;
+  int ldx, ldy;
+  int kh, kw, sh, sw, ph, pw;
+  int form;
+  int Hq, Wq;
+  long rows_per_phase;
+  mopoe_bn_ref bn_in;
+  mopoe_mask_ref mask;
+  double* out_stats;
+  mopoe_bn_ref relu_bn;
+  const bf16_t* xin;     // [rows_total][ldy]
+  double* bwd_sums;
+  unsigned x_bytes, w_bytes;
+  int nsplit;
+  float* partial;
+  long rows_total;
+  int out_f32;
+};
+
+__device__ __forceinline__ uint4 bldq(__amdgpu_buffer_rsrc_t srd, unsigned byte_off, unsigned s_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, s_off, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// 8 bf16 (one uint4) -> relu(x * scale + shift) -> 8 bf16; zero when !ok (spatial padding stays zero AFTER the transform)
+__device__ __forceinline__ uint4 bn_relu8(uint4 u, const float4& sc0, const float4& sc1, const float4& sh0, const float4& sh1, bool ok) {
+  auto f = [](float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.f); };
+  uint4 r;
+  r.x = pack_bf16(f(bf16_lo(u.x), sc0.x, sh0.x), f(bf16_hi(u.x), sc0.y, sh0.y));
+  r.y = pack_bf16(f(bf16_lo(u.y), sc0.z, sh0.z), f(bf16_hi(u.y), sc0.w, sh0.w));
+  r.z = pack_bf16(f(bf16_lo(u.z), sc1.x, sh1.x), f(bf16_hi(u.z), sc1.y, sh1.y));
+  r.w = pack_bf16(f(bf16_lo(u.w), sc1.z, sh1.z), f(bf16_hi(u.w), sc1.w, sh1.w));
+  return ok ? r : make_uint4(0u, 0u, 0u, 0u);
+}
+
+// fragment of the K-strided operand: element j of lane l = tile[k0 + 8 (l / 32) + j][c0 + l % 32] from an LDS image
+// stored [k][column] with row stride LD elements; two hardware-transposed 4 x 16 block reads
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int k0, int c0, int lane) {
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1, lhi = lane >> 5;
+  const bf16_t* p = tile + (k0 + lhi * 8 + (i16 >> 2)) * LD + c0 + g16 * 16 + (i16 & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * LD));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// SPEC: 1 forward, plain operand   2 forward, BN+ReLU on the operand   3 input gradient (weights K-contiguous)
+template <int BM, int BN, int WGM, int WGN, int SPEC>
+__global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const GemmArgsH a) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TI = WM / 32, TJ = WN / 32;
+  static_assert(TI >= 1 && TJ >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile is made of 32x32 MFMA tiles");
+  constexpr bool xform = SPEC == 2;
+  constexpr bool w_nk = SPEC == 3;
+  constexpr int A_LD = BKH + 8;                  // 80-byte rows
+  constexpr int BNK_LD = BKH + 8;
+  constexpr int BKN_LD = BN + 32;                // row stride = 64 (mod 256) bytes
+  constexpr int A_PER_THR = BM * 4 / NT;         // 16-byte pieces per thread (4 per tile row)
+  static_assert((BM * 4) % NT == 0 && A_PER_THR >= 1, "A tile pieces divide over the block");
+  constexpr int N8 = BN / 8;                     // pieces per k-row of the [k][n] weight tile
+  constexpr int B_PER_THR = w_nk ? BN * 4 / NT : (BKH * N8) / NT;
+  static_assert(w_nk ? (BN * 4) % NT == 0 : (BKH * N8) % NT == 0, "B tile pieces divide over the block");
+  static_assert(B_PER_THR >= 1, "B tile");
+  constexpr int B_ELEMS = w_nk ? BN * BNK_LD : BKH * BKN_LD;
+
+  __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * A_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float bnS[xform ? MAX_BN_C : 4];
+  __shared__ __attribute__((aligned(16))) float bnT[xform ? MAX_BN_C : 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int n0 = blockIdx.y * BN;
+  const int phase = blockIdx.z / a.nsplit;
+  const int split = blockIdx.z - phase * a.nsplit;
+
+  const TapWalk tw = tap_walk(a, phase);
+  const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
+  const int dsgn = tw.dsgn, cy = tw.cy, cx = tw.cx, phy = tw.phy, phx = tw.phx;
+  const int nkc = a.Ck / BKH;
+  const int total_all = nty * ntx * nkc;
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (int)a.w_bytes, 0x00020000);
+  const int per_split = (total_all + a.nsplit - 1) / a.nsplit;
+  const int it_beg = split * per_split;
+  const int it_end = it_beg + per_split < total_all ? it_beg + per_split : total_all;
+  const int total = it_end > it_beg ? it_end - it_beg : 0;
+
+  if (xform) {
+    for (int c = tid; c < a.Ck; c += NT) {
+      const BnC k = bn_coef(a.bn_in, c);
+      bnS[c] = k.scale;
+      bnT[c] = k.shift;
+    }
+    __syncthreads();
+  }
+
+  const int kq = tid & 3;            // 16-byte piece within a 64-byte tile row
+  const int trow = tid >> 2;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const int hw = a.Hq * a.Wq;
+
+  float cbias[TJ], s1[TJ], s2[TJ];
+  BnC rbc[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int n = n0 + wn * WN + j * 32 + l31;
+    s1[j] = s2[j] = 0.f;
+    cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
+    rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
+    if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+  }
+
+  // weight operand: per-thread byte offsets are fixed for the whole kernel, the K / tap advance is the scalar offset
+  unsigned voffB[B_PER_THR];
+#pragma unroll
+  for (int i = 0; i < B_PER_THR; ++i) {
+    if (w_nk) {
+      const int n = n0 + trow + i * (NT / 4);
+      voffB[i] = n < a.Cn ? ((unsigned)n * (unsigned)a.Cout_w + (unsigned)kq * 8u) * 2u : OOB;
+    } else {
+      const int p = tid + i * NT;
+      const int k = p / N8, n = n0 + (p % N8) * 8;
+      voffB[i] = n < a.Cn ? ((unsigned)k * (unsigned)a.Cout_w + (unsigned)n) * 2u : OOB;
+    }
+  }
+
+  const long nMt = (a.rows_per_phase + BM - 1) / BM;
+  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+    const long m0 = mt * BM;
+
+    int ry0[A_PER_THR], rx0[A_PER_THR], rbase[A_PER_THR];
+    bool rvalid[A_PER_THR];
+#pragma unroll
+    for (int i = 0; i < A_PER_THR; ++i) {
+      const long m = m0 + trow + i * (NT / 4);
+      rvalid[i] = m < a.rows_per_phase;
+      const unsigned mm = rvalid[i] ? (unsigned)m : 0u;
+      const int n = (int)(mm / (unsigned)hw);
+      const int rem = (int)(mm - (unsigned)n * (unsigned)hw);
+      const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
+      if (a.form == 0) { ry0[i] = qy * a.sh - a.ph; rx0[i] = qx * a.sw - a.pw; }
+      else             { ry0[i] = qy + cy;          rx0[i] = qx + cx; }
+      rbase[i] = (n * a.Hx + ry0[i]) * a.Wx + rx0[i];
+    }
+
+    uint4 ra[A_PER_THR], rb[B_PER_THR];
+    float4 psc0 = make_float4(0.f, 0.f, 0.f, 0.f), psc1 = psc0, psh0 = psc0, psh1 = psc0;
+    bool pend_ok[A_PER_THR];
+    int ld_tap = it_beg / nkc;
+    int ld_kc = (it_beg - ld_tap * nkc) * BKH;
+    bool tap_dirty = true;
+    unsigned offA[A_PER_THR], offW = 0;
+
+    auto load_tiles = [&]() {
+      if (tap_dirty) {
+        const int jy = ld_tap / ntx, jx = ld_tap - jy * ntx;
+        const int wtap = (ky0 + kstep_y * jy) * a.kw + (kx0 + kstep_x * jx);
+        const int tapoff = dsgn * (jy * a.Wx + jx);
+#pragma unroll
+        for (int i = 0; i < A_PER_THR; ++i) {
+          const int iy = ry0[i] + dsgn * jy, ix = rx0[i] + dsgn * jx;
+          const bool ok = rvalid[i] & ((unsigned)iy < (unsigned)a.Hx) & ((unsigned)ix < (unsigned)a.Wx);
+          offA[i] = ok ? ((unsigned)(rbase[i] + tapoff) * (unsigned)a.ldx + (unsigned)kq * 8u) * 2u : OOB;
+          pend_ok[i] = ok;
+        }
+        offW = (unsigned)wtap * (unsigned)a.Cin_w * (unsigned)a.Cout_w * 2u;
+        tap_dirty = false;
+      }
+      const unsigned sA = (unsigned)ld_kc * 2u;
+      const unsigned sB = offW + (w_nk ? (unsigned)ld_kc * 2u : (unsigned)ld_kc * (unsigned)a.Cout_w * 2u);
+      if (xform) {
+        psc0 = *reinterpret_cast<const float4*>(&bnS[ld_kc + kq * 8]);
+        psc1 = *reinterpret_cast<const float4*>(&bnS[ld_kc + kq * 8 + 4]);
+        psh0 = *reinterpret_cast<const float4*>(&bnT[ld_kc + kq * 8]);
+        psh1 = *reinterpret_cast<const float4*>(&bnT[ld_kc + kq * 8 + 4]);
+      }
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) ra[i] = bldq(srdX, offA[i], sA);
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) rb[i] = bldq(srdW, voffB[i], sB);
+      ld_kc += BKH;
+      if (ld_kc >= a.Ck) { ld_kc = 0; ++ld_tap; tap_dirty = true; }
+    };
+
+    auto store_tiles = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) {
+        const int r = trow + i * (NT / 4);
+        uint4 v = ra[i];
+        if (xform) v = bn_relu8(v, psc0, psc1, psh0, psh1, pend_ok[i]);
+        *reinterpret_cast<uint4*>(&As[buf][r * A_LD + kq * 8]) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) {
+        if (w_nk) {
+          const int r = trow + i * (NT / 4);
+          *reinterpret_cast<uint4*>(&Bs[buf][r * BNK_LD + kq * 8]) = rb[i];
+        } else {
+          const int p = tid + i * NT;
+          *reinterpret_cast<uint4*>(&Bs[buf][(p / N8) * BKN_LD + (p % N8) * 8]) = rb[i];
+        }
+      }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (total > 0) {
+      load_tiles();
+      store_tiles(std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+
+    auto chunk = [&](int it, auto curc) {
+      constexpr int cur = decltype(curc)::value;
+      // the scale/shift registers (psc/psh) and the validity flags (pend_ok, recomputed only when the tap changes)
+      // belong to the load issued HERE and are consumed by the store at the end of this chunk
+      if (it + 1 < total) load_tiles();
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMA block
+#pragma unroll
+      for (int s = 0; s < BKH / 16; ++s) {
+        bf16x8 av[TI], bv[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          av[i] = *reinterpret_cast<const bf16x8*>(&As[cur][(wm * WM + i * 32 + l31) * A_LD + s * 16 + lhi * 8]);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          if (w_nk) bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][(wn * WN + j * 32 + l31) * BNK_LD + s * 16 + lhi * 8]);
+          else bv[j] = tr_frag<BKN_LD>(&Bs[cur][0], s * 16, wn * WN + j * 32, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      if (it + 1 < total) store_tiles(std::integral_constant<int, cur ^ 1>{});
+      __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < total; it += 2) {
+      chunk(it, std::integral_constant<int, 0>{});
+      chunk(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (it < total) chunk(it, std::integral_constant<int, 0>{});
+
+    // ---- epilogue of this M tile: 32x32 accumulator layout row = (r & 3) + 8 (r >> 2) + 4 lhi, column = l31 ----------
+    bf16_t* __restrict__ Yh = reinterpret_cast<bf16_t*>(a.Y);
+    float* __restrict__ Yf = reinterpret_cast<float*>(a.Y);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        long yrows[4];
+        const float* mrows[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const long m = m0 + wm * WM + i * 32 + r4 + 8 * rg + 4 * lhi;
+          yrows[r4] = -1;
+          mrows[r4] = nullptr;
+          if (m < a.rows_per_phase) {
+            const unsigned mu = (unsigned)m;
+            const unsigned nn = mu / (unsigned)hw;
+            if (a.form == 0) {
+              yrows[r4] = m;
+            } else {
+              const unsigned rem = mu - nn * (unsigned)hw;
+              const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
+              yrows[r4] = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+            }
+            if (a.mask.kind == 1) mrows[r4] = a.mask.mask + (long)nn * a.Cn;
+            else if (a.mask.kind == 2) mrows[r4] = a.mask.mask + yrows[r4] * a.Cn;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int n = n0 + wn * WN + j * 32 + l31;
+          const bool nok = n < a.Cn;
+          float v[4];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const long yrow = yrows[r4];
+            const int r = rg * 4 + r4;
+            float x = acc[i][j][r];
+            if (a.partial) {   // split reduction: raw partial sums, finished by splitk_epilogue_bf16_kernel
+              if (yrow >= 0 && nok) a.partial[((long)split * a.rows_total + yrow) * a.Cn + n] = x;
+              v[r4] = 0.f;
+              continue;
+            }
+            x += cbias[j];
+            if (mrows[r4] && nok) x *= mrows[r4][n];
+            if (do_relu_bn) {
+              float xi = 0.f;
+              if (yrow >= 0 && nok) xi = bf16_to_f32(a.xin[yrow * a.ldy + n]);
+              x = (fmaf(xi, rbc[j].scale, rbc[j].shift) > 0.f) ? x : 0.f;
+              if (!a.out_f32) x = round_bf16(x);
+              if (yrow >= 0 && nok) { s1[j] += x; s2[j] += x * ((xi - rbc[j].mean) * rbc[j].rstd); }
+            } else {
+              if (!a.out_f32) x = round_bf16(x);
+              if (yrow >= 0 && nok) { s1[j] += x; s2[j] += x * x; }
+            }
+            v[r4] = x;
+          }
+          if (a.partial) continue;
+          if (a.out_f32) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              if (yrows[r4] >= 0 && nok) Yf[yrows[r4] * a.ldy + n] = v[r4];
+          } else {
+            // bf16 stores in pairs: lanes l (even column n) and l+1 hold columns n, n+1 of the same four rows; the even
+            // lane takes rows 0 and 2 of the group, the odd lane rows 1 and 3 -> every store is a 4-byte (n, n+1) pair.
+            // (Cn is even, so a valid even column has a valid right neighbour.)
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float mine = odd ? v[2 * h + 1] : v[2 * h];
+              const float send = odd ? v[2 * h] : v[2 * h + 1];
+              const float recv = __shfl_xor(send, 1, 64);
+              const long yrow = odd ? yrows[2 * h + 1] : yrows[2 * h];
+              const unsigned packed = odd ? pack_bf16(recv, mine) : pack_bf16(mine, recv);
+              const int nn = odd ? n - 1 : n;
+              if (yrow >= 0 && nok) *reinterpret_cast<unsigned*>(&Yh[yrow * a.ldy + nn]) = packed;
+            }
+          }
+        }
+      }
+    }
+  }
+
+#include "gemm_colstats.inc"
+}
+
+// ---- split reduction epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums --------
+__global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const GemmArgsH a) {
+  __shared__ float cs[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const bool nok = n < a.Cn;
+  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+  BnC rb = {0.f, 0.f, 0.f, 0.f};
+  if (nok && do_relu_bn) rb = bn_coef(a.relu_bn, n);
+  const long stride = a.rows_total * (long)a.Cn;
+  float s1 = 0.f, s2 = 0.f;
+  if (nok) {
+    for (long row = (long)blockIdx.y * 4 + ty; row < a.rows_total; row += (long)gridDim.y * 4) {
+      const float* p = a.partial + row * a.Cn + n;
+      float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < a.nsplit; ++s) acc4[s & 3] += p[(long)s * stride];
+      float x = bias + ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]));
+      if (a.mask.kind != 0) x *= mask_at(a.mask, row, n, a.Cn);
+      if (do_relu_bn) {
+        const float xi = bf16_to_f32(a.xin[row * a.ldy + n]);
+        x = (fmaf(xi, rb.scale, rb.shift) > 0.f) ? x : 0.f;
+        if (!a.out_f32) x = round_bf16(x);
+        s1 += x;
+        s2 += x * ((xi - rb.mean) * rb.rstd);
+      } else {
+        if (!a.out_f32) x = round_bf16(x);
+        s1 += x;
+        s2 += x * x;
+      }
+      if (a.out_f32) reinterpret_cast<float*>(a.Y)[row * a.ldy + n] = x;
+      else reinterpret_cast<bf16_t*>(a.Y)[row * a.ldy + n] = f32_to_bf16(x);
+    }
+  }
+  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
+  if (sums) {
+    cs[0][ty][tx] = s1;
+    cs[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && nok) {
+      atomic_add_f64(sums + n, (double)((cs[0][0][tx] + cs[0][1][tx]) + (cs[0][2][tx] + cs[0][3][tx])));
+      atomic_add_f64(sums + a.Cn + n, (double)((cs[1][0][tx] + cs[1][1][tx]) + (cs[1][2][tx] + cs[1][3][tx])));
+    }
+  }
+}
+
+// =====================================================================================================
+// weight gradient: dWp[tap][ci][co] (fp32) = sum over pixels of T(x)[pixel][ci] * dy[pixel][co]
+// K = pixels is the strided index of BOTH operands: both tiles are staged [pixel][channel] as they lie in memory and
+// both fragments come from transposed reads.  32 pixels per chunk; the pixel -> (image, y, x) split is shifts and
+// masks when the small grid is a power of two (every BASELINE shape), integer divisions otherwise.
+// =====================================================================================================
+struct WgradArgsH {
+  const bf16_t* Xs;
+  const bf16_t* Dy;
+  float* dW;
+  int N, Hs, Ws, Hb, Wb, Cin, Cout, kh, kw, sh, sw, ph, pw;
+  int x_is_big;
+  long Ms;
+  long chunk;
+  int nJ;
+  int atomic;
+  unsigned x_bytes, dy_bytes;
+  int lg_ws, lg_hw;      // log2 of Ws and Hs*Ws (POW2 kernels)
+  mopoe_bn_ref bn_in;
+};
+
+template <int BI, int BJ, bool XFORM, bool POW2>
+__global__ __launch_bounds__(256) void wgrad_gemm_bf16_kernel(const WgradArgsH a) {
+  constexpr int WI = BI / 2, WJ = BJ / 2, TI = WI / 32, TJ = WJ / 32;
+  constexpr int I_LD = BI + 32, J_LD = BJ + 32;   // row stride = 64 (mod 256) bytes
+  constexpr int I8 = BI / 8, J8 = BJ / 8;
+  constexpr int I_PER_THR = (BKH * I8) / 256, J_PER_THR = (BKH * J8) / 256;
+  static_assert(BI == BJ && I_PER_THR >= 1, "square tiles: both operands cover the same pixels per thread");
+
+  __shared__ __attribute__((aligned(16))) bf16_t Is[2][BKH * I_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Js[2][BKH * J_LD];
+  __shared__ __attribute__((aligned(16))) float bnS[XFORM ? MAX_BN_C : 4];
+  __shared__ __attribute__((aligned(16))) float bnT[XFORM ? MAX_BN_C : 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int it_i = blockIdx.x / a.nJ, it_j = blockIdx.x % a.nJ;
+  const int i0 = it_i * BI, j0 = it_j * BJ;
+  const int tap = blockIdx.y;
+  const int ky = tap / a.kw, kx = tap % a.kw;
+  const long mbeg = (long)blockIdx.z * a.chunk;
+  const long mend = mbeg + a.chunk < a.Ms ? mbeg + a.chunk : a.Ms;
+  const int total = (int)((mend - mbeg + BKH - 1) / BKH);
+
+  if (XFORM) {
+    for (int c = tid; c < a.Cin; c += 256) {
+      const BnC k = bn_coef(a.bn_in, c);
+      bnS[c] = k.scale;
+      bnT[c] = k.shift;
+    }
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xs, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdD = __builtin_amdgcn_make_buffer_rsrc((void*)a.Dy, 0, (int)a.dy_bytes, 0x00020000);
+
+  const int c8 = tid % I8;                        // this thread's 8-channel group (same for both operands: BI == BJ)
+  const int slot0 = tid / I8;                     // its pixel slot within a pass
+  constexpr int PPP = 256 / I8;                   // pixels per pass
+  const int ci = i0 + c8 * 8, cj = j0 + c8 * 8;
+  const bool ci_ok = ci < a.Cin, cj_ok = cj < a.Cout;
+  float4 sc0 = make_float4(0.f, 0.f, 0.f, 0.f), sc1 = sc0, sh0 = sc0, sh1 = sc0;
+  if (XFORM && ci_ok) {
+    sc0 = *reinterpret_cast<const float4*>(&bnS[ci]); sc1 = *reinterpret_cast<const float4*>(&bnS[ci + 4]);
+    sh0 = *reinterpret_cast<const float4*>(&bnT[ci]); sh1 = *reinterpret_cast<const float4*>(&bnT[ci + 4]);
+  }
+  const unsigned hw = (unsigned)(a.Hs * a.Ws);
+
+  uint4 ri[I_PER_THR], rj[J_PER_THR];
+  bool okx_reg[I_PER_THR];
+  unsigned m_next = (unsigned)mbeg;               // first pixel of the next chunk to load
+
+  auto load_tiles = [&]() {
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const unsigned m = m_next + (unsigned)(slot0 + t * PPP);
+      const bool inm = (long)m < mend;
+      unsigned n, qy, qx;
+      if (POW2) {
+        n = m >> a.lg_hw;
+        const unsigned rem = m & (hw - 1u);
+        qy = rem >> a.lg_ws;
+        qx = rem & ((unsigned)a.Ws - 1u);
+      } else {
+        n = m / hw;
+        const unsigned rem = m - n * hw;
+        qy = rem / (unsigned)a.Ws;
+        qx = rem - qy * (unsigned)a.Ws;
+      }
+      const int by = (int)qy * a.sh - a.ph + ky, bx = (int)qx * a.sw - a.pw + kx;
+      const bool inb = ((unsigned)by < (unsigned)a.Hb) & ((unsigned)bx < (unsigned)a.Wb);
+      const unsigned brow = (n * (unsigned)a.Hb + (unsigned)by) * (unsigned)a.Wb + (unsigned)bx;
+      const unsigned rowx = a.x_is_big ? brow : m, rowd = a.x_is_big ? m : brow;
+      const bool okx = inm & ci_ok & (a.x_is_big ? inb : true);
+      const bool okd = inm & cj_ok & (a.x_is_big ? true : inb);
+      ri[t] = bldq(srdX, okx ? (rowx * (unsigned)a.Cin + (unsigned)ci) * 2u : OOB, 0u);
+      rj[t] = bldq(srdD, okd ? (rowd * (unsigned)a.Cout + (unsigned)cj) * 2u : OOB, 0u);
+      okx_reg[t] = okx;
+    }
+    m_next += BKH;
+  };
+
+  auto store_tiles = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int t = 0; t < I_PER_THR; ++t) {
+      const int p = slot0 + t * PPP;
+      uint4 v = ri[t];
+      if (XFORM) v = bn_relu8(v, sc0, sc1, sh0, sh1, okx_reg[t]);
+      *reinterpret_cast<uint4*>(&Is[buf][p * I_LD + c8 * 8]) = v;
+      *reinterpret_cast<uint4*>(&Js[buf][p * J_LD + c8 * 8]) = rj[t];
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (total > 0) {
+    load_tiles();
+    store_tiles(std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+
+  auto chunk = [&](int it, auto curc) {
+    constexpr int cur = decltype(curc)::value;
+    if (it + 1 < total) load_tiles();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BKH / 16; ++s) {
+      bf16x8 av[TI], bv[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) av[i] = tr_frag<I_LD>(&Is[cur][0], s * 16, wi * WI + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bv[j] = tr_frag<J_LD>(&Js[cur][0], s * 16, wj * WJ + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < total) store_tiles(std::integral_constant<int, cur ^ 1>{});
+    __syncthreads();
+  };
+  int it = 0;
+  for (; it + 1 < total; it += 2) {
+    chunk(it, std::integral_constant<int, 0>{});
+    chunk(it + 1, std::integral_constant<int, 1>{});
+  }
+  if (it < total) chunk(it, std::integral_constant<int, 0>{});
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int co = j0 + wj * WJ + j * 32 + l31;
+    if (co >= a.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cii = i0 + wi * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (cii >= a.Cin) continue;
+        float* dst = a.dW + ((long)tap * a.Cin + cii) * a.Cout + co;
+        if (a.atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+        else *dst = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// host-side launchers
+// =====================================================================================================
+static int ilog2_exact(long v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1L << l) < v) ++l;
+  return l;
+}
+
+// tiles: 0 = 128x128 (4 waves)  1 = 256x64 (4 waves)  2 = 64x64 (4 waves)  3 = 256x128 (8 waves)  4 = 128x64 (4 waves)
+static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bias, void* Y, int out_f32,
+                              const mopoe_conv_geom* g, int dest_on_small, int Ck, int Cn, int w_nk,
+                              const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats,
+                              const mopoe_bn_ref* relu_bn, const bf16_t* xin, double* bwd_sums,
+                              const mopoe_conv_plan* plan, void* ws, size_t ws_bytes, hipStream_t stream) {
+  GemmArgsH a;
+  a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.out_f32 = out_f32;
+  a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;
+  a.ldx = Ck; a.ldy = Cn;
+  a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+  int nphase;
+  if (dest_on_small) {
+    a.form = 0; a.Hx = g->Hb; a.Wx = g->Wb; a.Hy = g->Hs; a.Wy = g->Ws; a.Hq = g->Hs; a.Wq = g->Ws; nphase = 1;
+  } else {
+    a.form = 1; a.Hx = g->Hs; a.Wx = g->Ws; a.Hy = g->Hb; a.Wy = g->Wb; a.Hq = g->Hb / g->sh; a.Wq = g->Wb / g->sw;
+    nphase = g->sh * g->sw;
+  }
+  a.rows_per_phase = (long)g->N * a.Hq * a.Wq;
+  a.rows_total = (long)g->N * a.Hy * a.Wy;
+  const size_t xb = (size_t)g->N * a.Hx * a.Wx * Ck * sizeof(bf16_t);
+  const size_t wb = (size_t)g->kh * g->kw * g->Cin * g->Cout * sizeof(bf16_t);
+  if (Ck % BKH != 0 || Cn % 8 != 0 || g->Cout % 8 != 0) {
+    set_error("bf16 conv: K channels must be a multiple of 32 and N channels of 8 (Ck = %d, Cn = %d)", Ck, Cn);
+    return MOPOE_ERR_ARG;
+  }
+  if (!aligned16(X) || !aligned16(W) || !aligned16(Y) || (xin && !aligned16(xin)) || xb >= (1ull << 31) || wb >= (1ull << 31)) {
+    set_error("bf16 conv: tensors must be 16-byte aligned and smaller than 2 GiB");
+    return MOPOE_ERR_ARG;
+  }
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wb;
+  mopoe_bn_ref none = {};
+  mopoe_mask_ref nomask = {nullptr, 0, 1};
+  a.bn_in = bn_in ? *bn_in : none;
+  a.mask = mask ? *mask : nomask;
+  a.out_stats = out_stats;
+  a.relu_bn = relu_bn ? *relu_bn : none;
+  a.xin = xin; a.bwd_sums = bwd_sums;
+  a.nsplit = 1; a.partial = nullptr;
+  if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
+  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
+  if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
+  if (a.mask.kind == 1 && a.mask.rows_per_sample != a.Hy * a.Wy) { set_error("channel mask: rows_per_sample must be Hout*Wout"); return MOPOE_ERR_ARG; }
+  if (a.rows_total >= (1L << 31) || (long)g->N * a.Hx * a.Wx >= (1L << 31)) { set_error("conv: more than 2^31 rows"); return MOPOE_ERR_ARG; }
+
+  int cfg;
+  if (Cn > 64) cfg = a.rows_per_phase >= 256L * 128 ? 3 : (a.rows_per_phase > 64 ? 0 : 2);
+  else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
+  if (plan && plan->tile >= 0) {
+    if (plan->tile > 4) { set_error("bf16 conv plan: tile %d (0..4)", plan->tile); return MOPOE_ERR_ARG; }
+    cfg = plan->tile;
+  }
+  static const int TILE_BM[5] = {128, 256, 64, 256, 128};
+  static const int TILE_BN[5] = {128, 64, 64, 128, 64};
+  const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
+  const long nMt = ceil_div(a.rows_per_phase, bm);
+  const int nNt = ceil_div(Cn, bn);
+  const int nkc = Ck / BKH;
+  const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
+  const long blocks = nMt * nNt * nphase;
+  const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
+  if (plan && plan->split > 0) {
+    long ns = std::min<long>(plan->split, iters);
+    if (ns >= 2 && (!ws || (size_t)ns * per > ws_bytes)) {
+      set_error("bf16 conv plan: split %ld needs %zu workspace bytes (have %zu)", ns, (size_t)ns * per, ws ? ws_bytes : (size_t)0);
+      return MOPOE_ERR_ARG;
+    }
+    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
+  } else if (ws && blocks < 256 && iters >= 8) {
+    long ns = std::min<long>((512 + blocks - 1) / blocks, (long)iters / 4);
+    if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
+    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
+  }
+  const long persist = cfg == 3 ? 512 : 768;
+  long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
+  const double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
+  const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
+  {
+    const int spec = w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1);
+    ProfScope prof(stream, flops, PROF_BF16_GATHER + cfg * 3 + (spec - 1));
+    dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
+#define MOPOE_LAUNCH_H(BM_, BN_, WM_, WN_)                                                                                          \
+  do {                                                                                                                            \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, stream, a);      \
+    else if (spec == 2) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
+    else hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM_, BN_, WM_, WN_, 3>), grid, dim3(64 * WM_ * WN_), 0, stream, a);                \
+  } while (0)
+    if (cfg == 0) MOPOE_LAUNCH_H(128, 128, 2, 2);
+    else if (cfg == 1) MOPOE_LAUNCH_H(256, 64, 4, 1);
+    else if (cfg == 3) MOPOE_LAUNCH_H(256, 128, 4, 2);
+    else if (cfg == 4) MOPOE_LAUNCH_H(128, 64, 4, 1);
+    else MOPOE_LAUNCH_H(64, 64, 2, 2);
+#undef MOPOE_LAUNCH_H
+    if (int rc = check_launch("gather_gemm_bf16")) return rc;
+    if (a.partial) {
+      dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), 256));
+      hipLaunchKernelGGL(splitk_epilogue_bf16_kernel, eg, dim3(256), 0, stream, a);
+      if (int rc = check_launch("splitk_epilogue_bf16")) return rc;
+    }
+  }
+  return MOPOE_OK;
+}
+
+}  // namespace mopoe
+
+using namespace mopoe;
+
+extern "C" int mopoe_conv_fwd_bf16(const uint16_t* x, const uint16_t* wp, const float* bias, void* y, int32_t y_is_f32,
+                                   const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
+                                   double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !wp || !y) { set_error("conv_fwd_bf16: null pointer"); return MOPOE_ERR_ARG; }
+  return launch_gather_bf16(x, wp, bias, y, y_is_f32, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask,
+                            out_stats, nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_dgrad_bf16(const uint16_t* dy, const uint16_t* wp, void* dx, int32_t dx_is_f32,
+                                     const mopoe_conv_geom* g, const mopoe_bn_ref* relu_bn, const uint16_t* xin,
+                                     double* bwd_sums, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!dy || !wp || !dx) { set_error("conv_dgrad_bf16: null pointer"); return MOPOE_ERR_ARG; }
+  return launch_gather_bf16(dy, wp, nullptr, dx, dx_is_f32, g, g->transposed ? 1 : 0, g->Cout, g->Cin, /*w_nk=*/1, nullptr,
+                            nullptr, nullptr, relu_bn, xin, bwd_sums, plan, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dwp, const mopoe_conv_geom* g,
+                                     const mopoe_bn_ref* bn_in, int32_t dwp_is_zero, const mopoe_conv_plan* plan,
+                                     void* stream_) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !dy || !dwp) { set_error("conv_wgrad_bf16: null pointer"); return MOPOE_ERR_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradArgsH a;
+  a.Xs = x; a.Dy = dy; a.dW = dwp;
+  a.N = g->N; a.Hs = g->Hs; a.Ws = g->Ws; a.Hb = g->Hb; a.Wb = g->Wb; a.Cin = g->Cin; a.Cout = g->Cout;
+  a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+  a.x_is_big = g->transposed ? 0 : 1;
+  a.Ms = (long)g->N * g->Hs * g->Ws;
+  mopoe_bn_ref none = {};
+  a.bn_in = bn_in ? *bn_in : none;
+  if (a.bn_in.mode != 0 && (a.bn_in.C != g->Cin || g->Cin > MAX_BN_C)) { set_error("wgrad bn_in channel mismatch"); return MOPOE_ERR_ARG; }
+  if (g->Cin % 8 != 0 || g->Cout % 8 != 0) { set_error("bf16 wgrad: channel counts must be multiples of 8 (%d, %d)", g->Cin, g->Cout); return MOPOE_ERR_ARG; }
+  const size_t rows_x = (size_t)g->N * (g->transposed ? g->Hs * g->Ws : g->Hb * g->Wb);
+  const size_t rows_dy = (size_t)g->N * (g->transposed ? g->Hb * g->Wb : g->Hs * g->Ws);
+  const size_t xb = rows_x * g->Cin * sizeof(bf16_t), db = rows_dy * g->Cout * sizeof(bf16_t);
+  if (!aligned16(x) || !aligned16(dy) || xb >= (1ull << 31) || db >= (1ull << 31)) {
+    set_error("bf16 wgrad: tensors must be 16-byte aligned and smaller than 2 GiB");
+    return MOPOE_ERR_ARG;
+  }
+  a.x_bytes = (unsigned)xb;
+  a.dy_bytes = (unsigned)db;
+  a.lg_ws = ilog2_exact(g->Ws);
+  a.lg_hw = ilog2_exact((long)g->Hs * g->Ws);
+  const bool pow2 = a.lg_ws >= 0 && a.lg_hw >= 0;
+  const int taps = g->kh * g->kw;
+  bool big = g->Cin > 64 && g->Cout > 64;
+  if (plan && plan->tile == 2) big = false;
+  const int T = big ? 128 : 64;
+  const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
+  a.nJ = nJ;
+  const long tiles = (long)nI * nJ * taps;
+  long split = (1024 + tiles - 1) / tiles;
+  if (plan && plan->split > 0) split = plan->split;
+  const long max_split = (a.Ms + 4 * BKH - 1) / (4 * BKH);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  long chunk = (a.Ms + split - 1) / split;
+  chunk = (chunk + BKH - 1) / BKH * BKH;
+  split = (a.Ms + chunk - 1) / chunk;
+  a.chunk = chunk;
+  a.atomic = split > 1;
+  const size_t bytes = (size_t)taps * g->Cin * g->Cout * sizeof(float);
+  if (a.atomic && !dwp_is_zero) {
+    if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
+  }
+  const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
+  const bool xf = a.bn_in.mode != 0;
+  ProfScope prof(stream, flops, PROF_BF16_WGRAD + (big ? 0 : 2) + (xf ? 1 : 0));
+  dim3 grid(nI * nJ, taps, (unsigned)split);
+#define MOPOE_LAUNCH_WH(T_)                                                                                              \
+  do {                                                                                                                 \
+    if (xf && pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_kernel<T_, T_, true, true>), grid, dim3(256), 0, stream, a);        \
+    else if (xf) hipLaunchKernelGGL((wgrad_gemm_bf16_kernel<T_, T_, true, false>), grid, dim3(256), 0, stream, a);          \
+    else if (pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_kernel<T_, T_, false, true>), grid, dim3(256), 0, stream, a);        \
+    else hipLaunchKernelGGL((wgrad_gemm_bf16_kernel<T_, T_, false, false>), grid, dim3(256), 0, stream, a);                 \
+  } while (0)
+  if (big) MOPOE_LAUNCH_WH(128);
+  else MOPOE_LAUNCH_WH(64);
+#undef MOPOE_LAUNCH_WH
+  return check_launch("wgrad_gemm_bf16");
+}
+
+// ---- image-side edge layers with the wide tensor in bf16 (the single-channel image, the taps and the tap gradients
+// stay fp32): stem forward / head input gradient, stem / head weight gradient, head forward ------------------------------
+extern "C" int mopoe_edge_expand_bf16(const float* scal, const float* w, uint16_t* out, const mopoe_conv_geom* g, int32_t C,
+                                      double* stats, void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!scal || !w || !out || !edge_supported(g, C, {w, out})) { set_error("edge_expand_bf16: needs k3 s2, C %% 4 == 0, aligned tensors"); return MOPOE_ERR_ARG; }
+  return edge_expand<bf16_t>(scal, w, out, g, C, stats, (hipStream_t)stream);
+}
+extern "C" int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, const mopoe_conv_geom* g, int32_t C,
+                                     void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!vec || !scal || !dw || !edge_supported(g, C, {vec, dw})) { set_error("edge_wgrad_bf16: needs k3 s2, C %% 4 == 0, aligned tensors"); return MOPOE_ERR_ARG; }
+  return edge_wgrad<bf16_t>(vec, scal, dw, g, C, (hipStream_t)stream);
+}
+extern "C" int mopoe_edge_reduce_bf16(const uint16_t* x, const float* w, const float* bias, float* out,
+                                      const mopoe_conv_geom* g, int32_t C, void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !w || !out || !edge_supported(g, C, {x, w})) { set_error("edge_reduce_bf16: needs k3 s2, C %% 4 == 0, aligned tensors"); return MOPOE_ERR_ARG; }
+  return edge_reduce<bf16_t>(x, w, bias, out, g, C, (hipStream_t)stream);
+}

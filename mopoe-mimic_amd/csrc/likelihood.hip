@@ -160,7 +160,14 @@ __global__ __launch_bounds__(256) void token_nll_bwd_kernel(const float* ids, co
 }
 
 // ---- embedding -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* ids, const float* table, float* out, long rows,
+template <typename T> __device__ __forceinline__ T to_store(float f);
+template <> __device__ __forceinline__ float to_store<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t to_store<bf16_t>(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ float from_store(float f) { return f; }
+__device__ __forceinline__ float from_store(bf16_t h) { return bf16_to_f32(h); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* ids, const float* table, T* out, long rows,
                                                           int V, int D) {
   // one wave per row chunk: lanes walk the D channels
   const long total = rows * D;
@@ -170,11 +177,12 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* ids, co
     const int d = (int)(i - r * D);
     int t = (int)ids[r];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    out[i] = table[(long)t * D + d];
+    out[i] = to_store<T>(table[(long)t * D + d]);
   }
 }
 
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* ids, const float* gout, float* dtable, long rows,
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* ids, const T* gout, float* dtable, long rows,
                                                           int V, int D, int padding_idx) {
   const long total = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* ids, co
     const int d = (int)(i - r * D);
     int t = (int)ids[r];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    if (t != padding_idx) unsafeAtomicAdd(dtable + (long)t * D + d, gout[i]);
+    if (t != padding_idx) unsafeAtomicAdd(dtable + (long)t * D + d, from_store(gout[i]));
   }
 }
 
@@ -313,9 +321,17 @@ extern "C" int mopoe_token_logprob_rows(const float* logp, const float* ids, int
 extern "C" int mopoe_embedding_fwd(const float* ids, const float* table, float* out, int64_t rows, int32_t V, int32_t D,
                                    void* stream) {
   if (!ids || !table || !out || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_fwd: bad arguments"); return MOPOE_ERR_ARG; }
-  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(stream_grid(rows * D, 4)), dim3(256), 0, (hipStream_t)stream, ids, table,
+  hipLaunchKernelGGL(embedding_fwd_kernel<float>, dim3(stream_grid(rows * D, 4)), dim3(256), 0, (hipStream_t)stream, ids, table,
                      out, (long)rows, V, D);
   return check_launch("embedding_fwd");
+}
+
+extern "C" int mopoe_embedding_fwd_bf16(const float* ids, const float* table, uint16_t* out, int64_t rows, int32_t V,
+                                        int32_t D, void* stream) {
+  if (!ids || !table || !out || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_fwd_bf16: bad arguments"); return MOPOE_ERR_ARG; }
+  hipLaunchKernelGGL(embedding_fwd_kernel<bf16_t>, dim3(stream_grid(rows * D, 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     table, out, (long)rows, V, D);
+  return check_launch("embedding_fwd_bf16");
 }
 
 extern "C" int mopoe_embedding_bwd(const float* ids, const float* gout, float* dtable, int64_t rows, int32_t V, int32_t D,
@@ -323,7 +339,17 @@ extern "C" int mopoe_embedding_bwd(const float* ids, const float* gout, float* d
   if (!ids || !gout || !dtable || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_bwd: bad arguments"); return MOPOE_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)V * D, st) != hipSuccess) { set_error("embedding_bwd memset failed"); return MOPOE_ERR_LAUNCH; }
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(stream_grid(rows * D, 4)), dim3(256), 0, st, ids, gout, dtable, (long)rows,
+  hipLaunchKernelGGL(embedding_bwd_kernel<float>, dim3(stream_grid(rows * D, 4)), dim3(256), 0, st, ids, gout, dtable, (long)rows,
                      V, D, padding_idx);
   return check_launch("embedding_bwd");
+}
+
+extern "C" int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtable, int64_t rows, int32_t V,
+                                        int32_t D, int32_t padding_idx, void* stream) {
+  if (!ids || !gout || !dtable || rows <= 0 || V <= 0 || D <= 0) { set_error("embedding_bwd_bf16: bad arguments"); return MOPOE_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)V * D, st) != hipSuccess) { set_error("embedding_bwd memset failed"); return MOPOE_ERR_LAUNCH; }
+  hipLaunchKernelGGL(embedding_bwd_kernel<bf16_t>, dim3(stream_grid(rows * D, 4)), dim3(256), 0, st, ids, gout, dtable,
+                     (long)rows, V, D, padding_idx);
+  return check_launch("embedding_bwd_bf16");
 }

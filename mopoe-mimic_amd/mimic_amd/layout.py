@@ -86,6 +86,46 @@ class PackedConv(nn.Module):
                                       error_msgs)
 
 
+class Bf16Weights:
+    """bf16 copies of a network's packed GEMM weights (the MFMA operands of the bf16 family): views into ONE flat
+    buffer, refreshed from the fp32 master parameters with one multi-tensor cast.  The same [taps, Cin, Cout] layout
+    serves the forward, the input gradient and (as destination layout) the weight gradient -- nothing is re-laid out."""
+
+    def __init__(self, mods):
+        self.mods = list(mods)
+        self.flat = None
+        self.views = {}
+        self.versions = None
+
+    def _build(self):
+        dev = self.mods[0].weight.device
+        total = sum(-(-m.weight.numel() // 8) * 8 for m in self.mods)      # every view 16-byte aligned
+        self.flat = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        off = 0
+        for m in self.mods:
+            n = m.weight.numel()
+            self.views[id(m)] = self.flat[off:off + n].view(m.weight.shape)
+            off += -(-n // 8) * 8
+        self.versions = None
+
+    def refresh(self, force: bool):
+        """force (training): the optimiser has stepped since the last forward.  Otherwise (eval) only when a master
+        tensor's version counter moved (load_state_dict, manual edits)."""
+        if self.flat is None or self.flat.device != self.mods[0].weight.device:
+            self._build()
+        vers = [m.weight._version for m in self.mods]
+        if force or vers != self.versions:
+            with torch.no_grad():
+                torch._foreach_copy_([self.views[id(m)] for m in self.mods], [m.weight.detach() for m in self.mods])
+            self.versions = vers
+
+    def get(self, mod):
+        return self.views[id(mod)]
+
+    def has(self, mod):
+        return id(mod) in self.views or any(m is mod for m in self.mods)
+
+
 class BnParams(nn.Module):
     """Affine parameters + running statistics of one BatchNorm (same keys as torch.nn.BatchNorm*d)."""
 

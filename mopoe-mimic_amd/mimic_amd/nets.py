@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layout import BnParams, Indexed, PackedConv, ResBlockParams
+from .layout import Bf16Weights, BnParams, Indexed, PackedConv, ResBlockParams
 from .ops import Geom
 from .trunk import (BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed, trunk_backward,
                     trunk_forward)
@@ -54,11 +54,46 @@ class _NetFn(torch.autograd.Function):
         return (None, None, *gin, *plist)
 
 
+def compute_dtype(flags):
+    """flags.compute_dtype: 'fp32' (default; BASELINE configs #1, #2, #4) or 'bf16' (configs #3, #5: bf16 storage of
+    activations / activation gradients / MFMA operands, fp32 accumulation, statistics, master weights and Adam)"""
+    name = str(getattr(flags, "compute_dtype", "fp32")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("fp32", "f32", "float32"):
+        return torch.float32
+    raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', not {name!r}")
+
+
 class _HipNet(nn.Module):
-    """Shared plumbing: parameter ordering, mask source, running-stat updates."""
+    """Shared plumbing: parameter ordering, mask source, running-stat updates, bf16 weight copies."""
 
     mask_source: MaskSource = MaskSource()
     dropout_enabled = True  # tests switch this off to reproduce the 'train_nodrop' fixtures
+    act_dtype = torch.float32
+    _shadow = None
+
+    def _init_dtype(self, flags, fp32_mods=()):
+        """fp32_mods: conv modules that stay on fp32 weights in the bf16 family (single-channel image-side layers, the
+        vocabulary head)"""
+        self.act_dtype = compute_dtype(flags)
+        if self.act_dtype == torch.bfloat16:
+            keep = {id(m) for m in fp32_mods}
+            mods = [m for m in self.modules() if isinstance(m, PackedConv) and id(m) not in keep]
+            object.__setattr__(self, "_shadow", Bf16Weights(mods))   # (not a submodule / buffer: derived state)
+
+    def _begin_forward(self):
+        if self._shadow is not None:
+            self._shadow.refresh(self.training)
+
+    def _w(self, mod):
+        """the weight tensor the kernels multiply: fp32 master, or its bf16 copy"""
+        if self._shadow is not None and self._shadow.has(mod):
+            return self._shadow.get(mod)
+        return mod.weight
+
+    def _bf16(self):
+        return self.act_dtype == torch.bfloat16
 
     def _named_param_list(self):
         if getattr(self, "_plist", None) is None:
@@ -111,25 +146,28 @@ class _Compressor(nn.Module):
         self.content_logvar = PackedConv(cin, cout, (), "linear", True)
 
 
-def _compress_fwd(comp: _Compressor, feat, batch):
+def _compress_fwd(comp: _Compressor, feat, batch, w=lambda m: m.weight):
+    """(mu, logvar) are fp32 in either family: they feed the fp32 latent kernel"""
     g = _lin_geom(comp.content_mu.cin, comp.content_mu.cout).with_batch(batch)
-    mu = ops.conv_fwd(feat, comp.content_mu.weight, g, bias=comp.content_mu.bias)
-    lv = ops.conv_fwd(feat, comp.content_logvar.weight, g, bias=comp.content_logvar.bias)
+    mu = ops.conv_fwd(feat, w(comp.content_mu), g, bias=comp.content_mu.bias, out_dtype=torch.float32)
+    lv = ops.conv_fwd(feat, w(comp.content_logvar), g, bias=comp.content_logvar.bias, out_dtype=torch.float32)
     return mu.view(batch, -1), lv.view(batch, -1), g
 
 
-def _compress_bwd(comp: _Compressor, feat, g, gmu, glv, grads, prefix):
+def _compress_bwd(comp: _Compressor, feat, g, gmu, glv, grads, prefix, w=lambda m: m.weight):
     batch = feat.shape[0]
     dfeat = None
     for name, mod, gg in (("content_mu", comp.content_mu, gmu), ("content_logvar", comp.content_logvar, glv)):
         if gg is None:
             continue
         gg4 = gg.reshape(batch, 1, 1, -1)
-        grads[f"{prefix}.{name}.weight"] = ops.conv_wgrad(feat, gg4, g)
         grads[f"{prefix}.{name}.bias"] = ops.colsum(gg4)
-        d = ops.conv_dgrad(gg4, mod.weight, g)
+        if feat.dtype != gg4.dtype:      # bf16 family: the gradient enters the GEMMs as a bf16 operand
+            gg4 = gg4.to(feat.dtype)
+        grads[f"{prefix}.{name}.weight"] = ops.conv_wgrad(feat, gg4, g)
+        d = ops.conv_dgrad(gg4, w(mod), g, out_dtype=torch.float32)   # the two halves are summed in fp32, stored once
         dfeat = d if dfeat is None else dfeat.add_(d)
-    return dfeat
+    return dfeat if dfeat is None or dfeat.dtype == feat.dtype else dfeat.to(feat.dtype)
 
 
 class EncoderImg(_HipNet):
@@ -152,12 +190,14 @@ class EncoderImg(_HipNet):
             self.blocks.append(BlockSpec(blk, g1, g2, True, f"feature_extractor.resblock_{i + 1}.0"))
             h = ho
         assert h == 1
+        self._init_dtype(flags, fp32_mods=[self.feature_extractor.conv1])
 
     def forward(self, x_img):
         mu, lv = self._call(x_img)
         return mu, lv
 
     def _run_forward(self, x_img):
+        self._begin_forward()
         b = x_img.shape[0]
         fe = self.feature_extractor
         x = x_img.reshape(b, x_img.shape[2], x_img.shape[3], x_img.shape[1]) if x_img.shape[1] == 1 \
@@ -166,21 +206,23 @@ class EncoderImg(_HipNet):
         arena = self._arena(self.blocks, x.device)
         gs = self.stem_geom.with_batch(b)
         st0 = arena.take(gs.Cout)
-        h0 = ops.conv_fwd(x, fe.conv1.weight, gs, out_stats=st0)
+        h0 = ops.conv_fwd(x, fe.conv1.weight, gs, out_stats=st0, out_dtype=self.act_dtype)
         feat, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
-                                             self.mask_source, arena, b)
-        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b)
+                                             self.mask_source, arena, b, self._w)
+        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b, self._w)
         if self.training:
             apply_running_updates(running)
         return (mu, lv), dict(x=x, feat=feat, trunk=saved, gs=gs, gl=gl, arena=arena)
 
     def _run_backward(self, sv, in_needs_grad, gmu, glv):
         grads: Dict[str, torch.Tensor] = {}
-        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w)
         grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["x"], g0, sv["gs"])
         gx = None
         if in_needs_grad[0]:
+            if self._bf16():
+                raise NotImplementedError("gradient w.r.t. the input image is not built for the bf16 family")
             gx = ops.conv_dgrad(g0, self.feature_extractor.conv1.weight, sv["gs"])
             gx = gx.reshape(gx.shape[0], 1, gx.shape[1], gx.shape[2]) if gx.shape[3] == 1 else gx.permute(0, 3, 1, 2)
         return [gx], grads, arena
@@ -229,6 +271,7 @@ class DecoderImg(_HipNet):
         self.head_geom = Geom(1, h, h, 2 * h, 2 * h, d, flags.image_channels, 3, 3, 2, 2, 1, 1, True)
         assert 2 * h == flags.img_size
         self._scale_cache = {}
+        self._init_dtype(flags, fp32_mods=[self.head])
 
     @property
     def head(self):
@@ -247,14 +290,15 @@ class DecoderImg(_HipNet):
         return img, self._scale(img.device)
 
     def _run_forward(self, z):
+        self._begin_forward()
         b = z.shape[0]
-        z4 = z.contiguous().view(b, 1, 1, -1)
+        z4 = z.contiguous().view(b, 1, 1, -1).to(self.act_dtype)
         arena = self._arena(self.blocks, z.device)
         gl = _lin_geom(self.feature_generator.cin, self.feature_generator.cout).with_batch(b)
         st0 = arena.take(gl.Cout)
-        h0 = ops.conv_fwd(z4, self.feature_generator.weight, gl, bias=self.feature_generator.bias, out_stats=st0)
+        h0 = ops.conv_fwd(z4, self._w(self.feature_generator), gl, bias=self.feature_generator.bias, out_stats=st0)
         ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
-                                           self.mask_source, arena, b)
+                                           self.mask_source, arena, b, self._w)
         gh = self.head_geom.with_batch(b)
         img = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
         if self.training:
@@ -271,11 +315,12 @@ class DecoderImg(_HipNet):
         k = len(self.blocks)
         grads[f"img_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], g4, sv["gh"])
         grads[f"img_generator.generator.{k}.bias"] = ops.colsum(g4)
-        dht = ops.conv_dgrad(g4, self.head.weight, sv["gh"])
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        dht = ops.conv_dgrad(g4, self.head.weight, sv["gh"], out_dtype=self.act_dtype)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)
-        gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
+        gz = ops.conv_dgrad(g0, self._w(self.feature_generator), sv["gl"], out_dtype=torch.float32).view(b, -1) \
+            if in_needs_grad[0] else None
         return [gz], grads, arena
 
 
@@ -324,23 +369,25 @@ class EncoderText(_HipNet):
             self.blocks.append(BlockSpec(blk, g1, g2, False, f"feature_extractor.resblock_{i + 1}.0"))
             w = wo
         assert w == 1, "text encoder must reduce the sequence to length 1"
+        self._init_dtype(flags)
 
     def forward(self, x_text):
         mu, lv = self._call(x_text)
         return mu, lv
 
     def _run_forward(self, ids):
+        self._begin_forward()
         b, length = ids.shape
         fe = self.feature_extractor
         ids = ids.contiguous()
-        emb = ops.embedding_fwd(ids, fe.embedding.weight).view(b, 1, length, -1)
+        emb = ops.embedding_fwd(ids, fe.embedding.weight, out_dtype=self.act_dtype).view(b, 1, length, -1)
         arena = self._arena(self.blocks, ids.device)
         gs = self.stem_geom.with_batch(b)
         st0 = arena.take(gs.Cout)
-        h0 = ops.conv_fwd(emb, fe.conv1.weight, gs, bias=fe.conv1.bias, out_stats=st0)
+        h0 = ops.conv_fwd(emb, self._w(fe.conv1), gs, bias=fe.conv1.bias, out_stats=st0)
         feat, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
-                                             self.mask_source, arena, b)
-        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b)
+                                             self.mask_source, arena, b, self._w)
+        mu, lv, gl = _compress_fwd(self.feature_compressor, feat, b, self._w)
         if self.training:
             apply_running_updates(running)
         return (mu, lv), dict(ids=ids, emb=emb, feat=feat, trunk=saved, gs=gs, gl=gl, arena=arena)
@@ -348,11 +395,11 @@ class EncoderText(_HipNet):
     def _run_backward(self, sv, in_needs_grad, gmu, glv):
         grads: Dict[str, torch.Tensor] = {}
         fe = self.feature_extractor
-        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor")
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads)
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w)
         grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, sv["gs"])
         grads["feature_extractor.conv1.bias"] = ops.colsum(g0)
-        demb = ops.conv_dgrad(g0, fe.conv1.weight, sv["gs"])
+        demb = ops.conv_dgrad(g0, self._w(fe.conv1), sv["gs"])
         grads["feature_extractor.embedding.weight"] = ops.embedding_bwd(sv["ids"], demb, fe.embedding.weight.shape[0], 0)
         return [None], grads, arena
 
@@ -398,6 +445,9 @@ class DecoderText(_HipNet):
             w = wo
         assert w == flags.len_sequence
         self.head_geom = Geom(1, 1, w, 1, w, d, flags.vocab_size, 1, 1, 1, 1, 0, 0, False)
+        # bf16 family: the vocabulary head (V = 3517 is not a multiple of 8) and the log-softmax run in fp32 on the
+        # fp32 master weight; its input / input gradient cross to and from bf16 at the head
+        self._init_dtype(flags, fp32_mods=[self.head])
 
     @property
     def head(self):
@@ -408,15 +458,18 @@ class DecoderText(_HipNet):
         return [logp]
 
     def _run_forward(self, z):
+        self._begin_forward()
         b = z.shape[0]
-        z4 = z.contiguous().view(b, 1, 1, -1)
+        z4 = z.contiguous().view(b, 1, 1, -1).to(self.act_dtype)
         arena = self._arena(self.blocks, z.device)
         gl = _lin_geom(self.feature_generator.cin, self.feature_generator.cout).with_batch(b)
         st0 = arena.take(gl.Cout)
-        h0 = ops.conv_fwd(z4, self.feature_generator.weight, gl, bias=self.feature_generator.bias, out_stats=st0)
+        h0 = ops.conv_fwd(z4, self._w(self.feature_generator), gl, bias=self.feature_generator.bias, out_stats=st0)
         ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
-                                           self.mask_source, arena, b)
+                                           self.mask_source, arena, b, self._w)
         gh = self.head_geom.with_batch(b)
+        if self._bf16():
+            ht = ht.float()
         logits = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
         logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
         if self.training:
@@ -432,8 +485,11 @@ class DecoderText(_HipNet):
         grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
         grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)
         dht = ops.conv_dgrad(glogits, self.head.weight, gh)
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads)
+        if self._bf16():
+            dht = dht.to(self.act_dtype)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)
-        gz = ops.conv_dgrad(g0, self.feature_generator.weight, sv["gl"]).view(b, -1) if in_needs_grad[0] else None
+        gz = ops.conv_dgrad(g0, self._w(self.feature_generator), sv["gl"], out_dtype=torch.float32).view(b, -1) \
+            if in_needs_grad[0] else None
         return [gz], grads, arena

@@ -4,7 +4,9 @@ There is deliberately no CPU / eager fallback here: if the HIP library is missin
 not on a GPU the ops raise.  (CPU tests of the host logic monkeypatch this module's functions with
 the torch emulation under tests/, which is test infrastructure, not a product path.)
 
-Every function takes/returns channels-last fp32 tensors (see the header for the layout contract).
+Every function takes/returns channels-last tensors (see the header for the layout contract): fp32, or -- the bf16
+storage family of BASELINE configs #3 / #5 -- bfloat16 activations and bf16 weight copies with fp32 accumulation; the
+entry point is chosen by the dtype of the activation operand.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -401,14 +403,71 @@ def _tuned_plan(key, cands_fn, launch):
     return None if best is None else C.byref(best)
 
 
+BF16 = torch.bfloat16
+_GATHER_TILES_BF16 = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64))
+
+
+def _is16(t):
+    return t is not None and t.dtype == BF16
+
+
+def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int):
+    rows, nphase, taps, ck, cn = _gather_shape(kind, g)
+    iters = taps * (ck // 32)
+    per = rows * nphase * cn * 4
+    cands = {}
+    for tile, (bm, bn) in enumerate(_GATHER_TILES_BF16):
+        blocks = -(-rows // bm) * -(-cn // bn) * nphase
+        if bm == 256 and rows < 256:
+            continue
+        cap = 512 if tile == 3 else 768
+        cands[(tile, 1)] = min(1.0, blocks / cap)
+        for sp in _SPLITS:
+            if sp * 2 <= iters and blocks * sp <= 2048 and sp * per <= ws_bytes:
+                cands[(tile, sp)] = min(1.0, blocks * sp / cap)
+    return cands
+
+
 def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Optional[Mask] = None,
-             out_stats=None):
+             out_stats=None, out_dtype=None):
+    """out_dtype: dtype of the result (default: the activation operand's).  bf16 family: x bf16 + wp bf16 (the
+    weight copy); the single-channel image-side layers take the fp32 image / fp32 taps and a bf16 wide tensor."""
     _dev(x, wp, bias, out_stats)
     assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
-    y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
+    out_dtype = out_dtype or x.dtype
     gc = g.c()
+    stream = _stream()
+    if _is16(x) or out_dtype == BF16:
+        plain = bn_in is None and mask is None
+        if not g.transposed and g.Cin == 1:      # image stem: fp32 pixels x fp32 taps -> bf16 features
+            assert plain and bias is None and x.dtype == torch.float32 and wp.dtype == torch.float32
+            y = torch.empty(g.out_shape, dtype=BF16, device=x.device)
+            _check(lib().mopoe_edge_expand_bf16(_p(x), _p(wp), _p(y), C.byref(gc), g.Cout, _p(out_stats), stream))
+            return y
+        if g.transposed and g.Cout == 1:         # image head: bf16 features x fp32 taps -> fp32 pixels
+            assert plain and out_stats is None and _is16(x) and wp.dtype == torch.float32
+            y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
+            _check(lib().mopoe_edge_reduce_bf16(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), g.Cin, stream))
+            return y
+        if not (_is16(x) and _is16(wp)):
+            raise MopoeHipError("bf16 conv needs a bf16 activation and the bf16 copy of the packed weight")
+        y = torch.empty(g.out_shape, dtype=out_dtype, device=x.device)
+        ws, nbytes = _workspace(x.device)
+        fn = lib().mopoe_conv_fwd_bf16
+        bnr, mr, f32 = _bn(bn_in), _mask(mask), C.c_int32(int(out_dtype == torch.float32))
+
+        def launch16(plan, stats=None):
+            _check(fn(_p(x), _p(wp), _p(bias), _p(y), f32, C.byref(gc), bnr, mr, _p(stats), plan, _p(ws),
+                      C.c_size_t(nbytes), stream))
+
+        key = ("fwd16", g, bn_in is not None, mask is not None, out_stats is not None, out_dtype)
+        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("fwd", g, nbytes),
+                           lambda ref: launch16(ref, _scratch_like(out_stats)))
+        launch16(plan, out_stats)
+        return y
+    y = torch.empty(g.out_shape, dtype=torch.float32, device=x.device)
     ws, nbytes = _workspace(x.device)
-    fn, stream = lib().mopoe_conv_fwd, _stream()
+    fn = lib().mopoe_conv_fwd
     bnr, mr = _bn(bn_in), _mask(mask)
 
     def launch(plan, stats=None):
@@ -422,13 +481,37 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
     return y
 
 
-def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums=None):
+def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums=None, out_dtype=None):
     _dev(dy, wp, xin, bwd_sums)
     assert tuple(dy.shape) == g.out_shape
-    dx = torch.empty(g.in_shape, dtype=torch.float32, device=dy.device)
+    out_dtype = out_dtype or dy.dtype
     gc = g.c()
+    stream = _stream()
+    if _is16(dy) or out_dtype == BF16:
+        if g.transposed and g.Cout == 1:         # image head: fp32 pixel gradient x fp32 taps -> bf16 feature gradient
+            assert relu_bn is None and dy.dtype == torch.float32 and wp.dtype == torch.float32
+            dx = torch.empty(g.in_shape, dtype=BF16, device=dy.device)
+            _check(lib().mopoe_edge_expand_bf16(_p(dy), _p(wp), _p(dx), C.byref(gc), g.Cin, None, stream))
+            return dx
+        if not (_is16(dy) and _is16(wp)) or (xin is not None and not _is16(xin)):
+            raise MopoeHipError("bf16 conv_dgrad needs bf16 dy / xin and the bf16 copy of the packed weight")
+        dx = torch.empty(g.in_shape, dtype=out_dtype, device=dy.device)
+        ws, nbytes = _workspace(dy.device)
+        fn = lib().mopoe_conv_dgrad_bf16
+        bnr, f32 = _bn(relu_bn), C.c_int32(int(out_dtype == torch.float32))
+
+        def launch16(plan, sums=None):
+            _check(fn(_p(dy), _p(wp), _p(dx), f32, C.byref(gc), bnr, _p(xin), _p(sums), plan, _p(ws), C.c_size_t(nbytes),
+                      stream))
+
+        key = ("dgrad16", g, relu_bn is not None, bwd_sums is not None, out_dtype)
+        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("dgrad", g, nbytes),
+                           lambda ref: launch16(ref, _scratch_like(bwd_sums)))
+        launch16(plan, bwd_sums)
+        return dx
+    dx = torch.empty(g.in_shape, dtype=torch.float32, device=dy.device)
     ws, nbytes = _workspace(dy.device)
-    fn, stream = lib().mopoe_conv_dgrad, _stream()
+    fn = lib().mopoe_conv_dgrad
     bnr = _bn(relu_bn)
 
     def launch(plan, sums=None):
@@ -442,19 +525,33 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
 
 
 def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
-    """out: optional ZERO-FILLED [taps, Cin, Cout] destination (e.g. a slice of a per-network gradient arena)."""
+    """out: optional ZERO-FILLED [taps, Cin, Cout] destination (e.g. a slice of a per-network gradient arena).
+    The result is fp32 for either family (it feeds Adam on the fp32 master weights)."""
     _dev(x, dy, out)
     assert tuple(x.shape) == g.in_shape and tuple(dy.shape) == g.out_shape
     dwp = out if out is not None else torch.empty((g.taps, g.Cin, g.Cout), dtype=torch.float32, device=x.device)
-    assert tuple(dwp.shape) == (g.taps, g.Cin, g.Cout)
+    assert tuple(dwp.shape) == (g.taps, g.Cin, g.Cout) and dwp.dtype == torch.float32
     gc = g.c()
-    fn, stream = lib().mopoe_conv_wgrad, _stream()
+    stream = _stream()
     bnr = _bn(bn_in)
+    if _is16(x) or _is16(dy):
+        if min(g.Cin, g.Cout) == 1:              # image stem / head: wide tensor bf16, image side fp32
+            assert bn_in is None
+            vec, scal = (dy, x) if g.Cin == 1 else (x, dy)
+            assert _is16(vec) and scal.dtype == torch.float32
+            _check(lib().mopoe_edge_wgrad_bf16(_p(vec), _p(scal), _p(dwp), C.byref(gc), max(g.Cin, g.Cout), stream))
+            return dwp
+        if not (_is16(x) and _is16(dy)):
+            raise MopoeHipError("bf16 conv_wgrad needs both operands in bf16")
+        fn = lib().mopoe_conv_wgrad_bf16
+        key = ("wgrad16", g, bn_in is not None)
+    else:
+        fn = lib().mopoe_conv_wgrad
+        key = ("wgrad", g, bn_in is not None)
 
     def launch(plan, dst, is_zero):
         _check(fn(_p(x), _p(dy), _p(dst), C.byref(gc), bnr, C.c_int32(is_zero), plan, stream))
 
-    key = ("wgrad", g, bn_in is not None)
     plan = _tuned_plan(key, lambda: _wgrad_candidates(g), lambda ref: launch(ref, _scratch_like(dwp), 1))
     launch(plan, dwp, int(out is not None))
     return dwp
@@ -470,7 +567,8 @@ def _rows(t):
 def block_out_fwd(s, m, bn_s: Bn, a=RES_A, b=RES_B, out_stats=None):
     _dev(s, m, out_stats)
     out = torch.empty_like(s)
-    _check(lib().mopoe_block_out_fwd(_p(s), _p(m), _p(out), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s),
+    fn = lib().mopoe_block_out_fwd_bf16 if _is16(s) else lib().mopoe_block_out_fwd
+    _check(fn(_p(s), _p(m), _p(out), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s),
                                      C.c_float(a), C.c_float(b), _p(out_stats), _stream()))
     return out
 
@@ -480,8 +578,8 @@ def bn_bwd_reduce(g, s, bn_s: Bn, sums=None):
     _dev(g, s, sums)
     if sums is None:
         sums = new_stats(s.shape[-1], s.device)
-    _check(lib().mopoe_bn_bwd_reduce(_p(g), _p(s), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s), _p(sums),
-                                     _stream()))
+    fn = lib().mopoe_bn_bwd_reduce_bf16 if _is16(s) else lib().mopoe_bn_bwd_reduce
+    _check(fn(_p(g), _p(s), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s), _p(sums), _stream()))
     return sums
 
 
@@ -496,9 +594,9 @@ def block_out_bwd(g, s, bn_s: Bn, sums, mask: Optional[Mask], a=RES_A, b=RES_B, 
         small = torch.zeros(4, c, dtype=torch.float32, device=g.device)
     cdm = small[2] if want_colsum_dm else None
     cds = small[3] if want_colsum_ds else None
-    _check(lib().mopoe_block_out_bwd(_p(g), _p(s), _p(dm), _p(ds), C.c_int64(_rows(s)), c, _bn(bn_s),
-                                     _p(sums), _mask(mask), C.c_float(a), C.c_float(b), _p(small[0]),
-                                     _p(small[1]), _p(cdm), _p(cds), _stream()))
+    fn = lib().mopoe_block_out_bwd_bf16 if _is16(s) else lib().mopoe_block_out_bwd
+    _check(fn(_p(g), _p(s), _p(dm), _p(ds), C.c_int64(_rows(s)), c, _bn(bn_s), _p(sums), _mask(mask), C.c_float(a),
+              C.c_float(b), _p(small[0]), _p(small[1]), _p(cdm), _p(cds), _stream()))
     return dm, ds, small[0], small[1], cdm, cds
 
 
@@ -513,9 +611,9 @@ def bn_bwd_apply(dy, x, bn: Bn, sums, mask: Optional[Mask] = None, add=None, wan
         small = torch.zeros(3, c, dtype=torch.float32, device=x.device)
     cs = small[2] if want_colsum else None
     nb = _bn(next_bn) if next_s is not None else None
-    _check(lib().mopoe_bn_bwd_apply(_p(dy), _p(x), _p(add), _p(dx), C.c_int64(_rows(x)), c, _bn(bn), _p(sums),
-                                    _mask(mask), _p(small[0]), _p(small[1]), _p(cs), _p(next_s), nb, _p(next_sums),
-                                    _stream()))
+    fn = lib().mopoe_bn_bwd_apply_bf16 if _is16(x) else lib().mopoe_bn_bwd_apply
+    _check(fn(_p(dy), _p(x), _p(add), _p(dx), C.c_int64(_rows(x)), c, _bn(bn), _p(sums), _mask(mask), _p(small[0]),
+              _p(small[1]), _p(cs), _p(next_s), nb, _p(next_sums), _stream()))
     return dx, small[0], small[1], cs
 
 
@@ -535,7 +633,8 @@ def bn_running_update(entries: Sequence, momentum=0.1):
 def colsum(x):
     _dev(x)
     out = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device)
-    _check(lib().mopoe_colsum(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], _stream()))
+    fn = lib().mopoe_colsum_bf16 if _is16(x) else lib().mopoe_colsum
+    _check(fn(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], _stream()))
     return out
 
 
@@ -668,19 +767,20 @@ def token_logprob_rows(logp, ids):
     return out
 
 
-def embedding_fwd(ids, table):
+def embedding_fwd(ids, table, out_dtype=None):
     _dev(ids, table)
-    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
-    _check(lib().mopoe_embedding_fwd(_p(ids), _p(table), _p(out), C.c_int64(ids.numel()), table.shape[0],
-                                     table.shape[1], _stream()))
+    out_dtype = out_dtype or torch.float32
+    out = torch.empty(*ids.shape, table.shape[1], dtype=out_dtype, device=table.device)
+    fn = lib().mopoe_embedding_fwd_bf16 if out_dtype == BF16 else lib().mopoe_embedding_fwd
+    _check(fn(_p(ids), _p(table), _p(out), C.c_int64(ids.numel()), table.shape[0], table.shape[1], _stream()))
     return out
 
 
 def embedding_bwd(ids, gout, vocab, padding_idx=0):
     _dev(ids, gout)
     dtable = torch.empty(vocab, gout.shape[-1], dtype=torch.float32, device=gout.device)
-    _check(lib().mopoe_embedding_bwd(_p(ids), _p(gout), _p(dtable), C.c_int64(ids.numel()), vocab, gout.shape[-1],
-                                     padding_idx, _stream()))
+    fn = lib().mopoe_embedding_bwd_bf16 if _is16(gout) else lib().mopoe_embedding_bwd
+    _check(fn(_p(ids), _p(gout), _p(dtable), C.c_int64(ids.numel()), vocab, gout.shape[-1], padding_idx, _stream()))
     return dtable
 
 
@@ -697,7 +797,13 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 60
+    names = [None] * 80
+    for tile, tt in enumerate(("128, 128, 2, 2", "256, 64, 4, 1", "64, 64, 2, 2", "256, 128, 4, 2", "128, 64, 4, 1")):
+        for spec in (1, 2, 3):
+            names[60 + tile * 3 + spec - 1] = f"gather_gemm_bf16_kernel<{tt}, {spec}>"
+    for i, tt in enumerate(("128, 128", "64, 64")):
+        for xf in (0, 1):
+            names[75 + 2 * i + xf] = f"wgrad_gemm_bf16_kernel<{tt}, {'true' if xf else 'false'}, true>"
     for tile, tt in enumerate(_TILE_TEMPLATES):
         for spec in range(4):
             names[tile * 4 + spec] = f"gather_gemm_kernel<{tt}, true, {spec}>"

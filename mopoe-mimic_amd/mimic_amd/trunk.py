@@ -147,9 +147,14 @@ class StatsArena:
         return v
 
 
+def _master_weight(mod):
+    return mod.weight
+
+
 def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: bool, masks: MaskSource,
-                  arena: StatsArena, batch: int):
+                  arena: StatsArena, batch: int, wsel=_master_weight):
     """x: [N,H,W,C] output of the stem, x_stats: its column statistics (train) or None (eval).
+    wsel(conv module) -> the weight tensor the kernels multiply (fp32 master, or its bf16 copy in the bf16 family).
     Returns (out, saved) where saved is the per-block state the backward needs."""
     saved = []
     running = []
@@ -174,8 +179,8 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         st_d1 = arena.take(g1.Cout)
         st_s = arena.take(g2.Cout)
         sconv, sbn = p.short[0], p.short[1]
-        s = lane.run(lambda: ops.conv_fwd(x, sconv.weight, g2, bias=sconv.bias, out_stats=st_s), x)
-        d1 = ops.conv_fwd(x, p.conv1.weight, g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
+        s = lane.run(lambda: ops.conv_fwd(x, wsel(sconv), g2, bias=sconv.bias, out_stats=st_s), x)
+        d1 = ops.conv_fwd(x, wsel(p.conv1), g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
         bn2 = _bn(p.bn2, training, st_d1, rows_in)
         if training:
             running.append((st_d1, p.bn2, rows_in))
@@ -183,7 +188,7 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         rps_out = rows_out // batch
         if dropout:
             mask2 = masks.get(spec.name + ".dropout2", batch, rps_out, g2.Cout, spec.twod, x.device)
-        m = ops.conv_fwd(d1, p.conv2.weight, g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
+        m = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
         lane.join()
         bns = _bn(sbn, training, st_s, rows_out)
         if training:
@@ -195,7 +200,7 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
     return x, saved, running
 
 
-def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor]):
+def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor], wsel=_master_weight):
     """g: gradient w.r.t. the trunk output.  Fills ``grads`` (keyed by parameter name relative to the
     network) and returns (gradient w.r.t. the trunk input, gradient arena).  Every gradient of the trunk's
     parameters is a view into the arena, so data parallelism can all-reduce a whole network with one
@@ -242,11 +247,11 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                        want_colsum_dm=has_bias, want_colsum_ds=True,
                                                        small=take_f(4, g2.Cout))
         sums2 = take_d(g1.Cout)
-        dh2 = ops.conv_dgrad(dm, p.conv2.weight, g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
+        dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
         w2, ws_ = take_w(g2), take_w(g2)
         grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=w2), d1, dm)
         grads[f"{n}.{p.short_name}.0.weight"] = lane.run(lambda: ops.conv_wgrad(x, ds, g2, out=ws_), x, ds)
-        dxs = lane_s.run(lambda: ops.conv_dgrad(ds, p.short[0].weight, g2), ds)
+        dxs = lane_s.run(lambda: ops.conv_dgrad(ds, wsel(p.short[0]), g2), ds)
         grads[f"{n}.{p.short_name}.0.bias"] = cds
         grads[f"{n}.{p.short_name}.1.weight"] = dgs
         grads[f"{n}.{p.short_name}.1.bias"] = dbs
@@ -254,7 +259,7 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                small=take_f(3, g1.Cin))
         grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
         sums1 = take_d(g1.Cin)
-        dh1 = ops.conv_dgrad(dc1, p.conv1.weight, g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
+        dh1 = ops.conv_dgrad(dc1, wsel(p.conv1), g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
         w1 = take_w(g1)
         grads[f"{n}.conv1.weight"] = lane.run(lambda: ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=w1), x, dc1)
         if has_bias:

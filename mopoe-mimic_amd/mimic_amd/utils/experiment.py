@@ -31,6 +31,7 @@ def default_flags(**overrides) -> argparse.Namespace:
         # (evaluated only when the caller passes no device: a launcher process must not initialise the GPU)
         device=overrides["device"] if "device" in overrides else torch.device("cuda" if torch.cuda.is_available() else "cpu"),
         start_epoch=0, end_epoch=1, eval_freq=10, world_size=1, dataloader_workers=0, weighted_sampler=False,
+        compute_dtype="fp32",   # 'bf16': bf16 storage + bf16 MFMA with fp32 accumulation (BASELINE configs #3, #5)
         mm_vae_save="mm_vae", start_early_stopping_epoch=0, max_early_stopping_index=5, testing_batches=2,
         encoder_save_m1="encoderM1", encoder_save_m2="encoderM2", encoder_save_m3="encoderM3",
         decoder_save_m1="decoderM1", decoder_save_m2="decoderM2", decoder_save_m3="decoderM3",

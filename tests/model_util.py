@@ -6,10 +6,11 @@ from mimic_amd.utils.experiment import HotPathExperiment, default_flags
 from mimic_amd import nets
 
 
-def build_exp(cfg: R.Cfg, sd, device, mode="train_nodrop", masks=None, eps=None):
+def build_exp(cfg: R.Cfg, sd, device, mode="train_nodrop", masks=None, eps=None, compute_dtype="fp32"):
     flags = default_flags(img_size=cfg.img_size, class_dim=cfg.class_dim, DIM_img=cfg.DIM_img,
                           DIM_text=cfg.DIM_text, vocab_size=cfg.vocab_size, batch_size=cfg.batch_size,
-                          beta=cfg.beta, beta_content=cfg.beta_content, device=torch.device(device))
+                          beta=cfg.beta, beta_content=cfg.beta_content, device=torch.device(device),
+                          compute_dtype=compute_dtype)
     exp = HotPathExperiment(flags)
     model = exp.mm_vae
     missing = model.load_state_dict(sd, strict=True)

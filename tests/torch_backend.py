@@ -84,39 +84,70 @@ def _accum(stats, y):
         stats[1] += (y2 * y2).sum(0)
 
 
+# ---- bf16 storage family: the same arithmetic with the kernels' rounding points -------------------------------------
+# (operands after BN+ReLU and every stored result are rounded to bfloat16; sums stay fp32; statistics and reductions are
+# taken over the STORED values -- include/mopoe_hip.h, "bf16 storage family")
+BF16 = torch.bfloat16
+
+
+def _f(t):
+    return t.float() if (t is not None and t.dtype == BF16) else t
+
+
+def _q16(t):
+    """value after a round trip through bf16 storage, kept in fp32"""
+    return t.to(BF16).float()
+
+
+def _act16(x, bn):
+    """MFMA operand: relu(bn(x)) rounded to bf16 when the activation is stored in bf16"""
+    h = _act(_f(x), bn)
+    return _q16(h) if (x.dtype == BF16 and bn is not None) else h
+
+
 # ---- convolution family ------------------------------------------------------------------------
-def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None):
+def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None, out_dtype=None):
     assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
-    h = _act(x, bn_in).permute(0, 3, 1, 2)
-    y = _conv_nchw(h, _ref_weight(wp, g), g).permute(0, 2, 3, 1).contiguous()
+    out_dtype = out_dtype or x.dtype
+    if g.transposed and g.Cout == 1 and x.dtype == BF16:
+        out_dtype = torch.float32            # image head of the bf16 family: fp32 pixels
+    h = _act16(x, bn_in).permute(0, 3, 1, 2)
+    y = _conv_nchw(h, _ref_weight(_f(wp), g), g).permute(0, 2, 3, 1).contiguous()
     assert tuple(y.shape) == g.out_shape, (y.shape, g)
     if bias is not None:
         y = y + bias
     mm = _mask_mult(y, mask)
     if mm is not None:
         y = y * mm
+    if out_dtype == BF16:
+        y = _q16(y)
     _accum(out_stats, y)
-    return y
+    return y.to(out_dtype)
 
 
-def conv_dgrad(dy, wp, g: Geom, relu_bn=None, xin=None, bwd_sums=None):
+def conv_dgrad(dy, wp, g: Geom, relu_bn=None, xin=None, bwd_sums=None, out_dtype=None):
+    out_dtype = out_dtype or dy.dtype
+    dy, xin = _f(dy), _f(xin)
     x0 = torch.zeros(g.in_shape, dtype=dy.dtype, device=dy.device).permute(0, 3, 1, 2).requires_grad_(True)
     with torch.enable_grad():
-        y = _conv_nchw(x0, _ref_weight(wp, g), g)
+        y = _conv_nchw(x0, _ref_weight(_f(wp), g), g)
     (dx,) = torch.autograd.grad(y, x0, dy.permute(0, 3, 1, 2))
     dx = dx.permute(0, 2, 3, 1).contiguous()
     if relu_bn is not None:
         mean, rstd, scale, shift = bn_coef(relu_bn)
         dx = dx * ((xin * scale + shift) > 0).to(dx.dtype)
-        if bwd_sums is not None:
-            xhat = (xin - mean) * rstd
-            bwd_sums[0] += dx.reshape(-1, dx.shape[-1]).double().sum(0)
-            bwd_sums[1] += (dx * xhat).reshape(-1, dx.shape[-1]).double().sum(0)
-    return dx
+    if out_dtype == BF16:
+        dx = _q16(dx)
+    if relu_bn is not None and bwd_sums is not None:
+        xhat = (xin - mean) * rstd
+        bwd_sums[0] += dx.reshape(-1, dx.shape[-1]).double().sum(0)
+        bwd_sums[1] += (dx * xhat).reshape(-1, dx.shape[-1]).double().sum(0)
+    return dx.to(out_dtype)
 
 
 def conv_wgrad(x, dy, g: Geom, bn_in=None, out=None):
-    h = _act(x, bn_in).permute(0, 3, 1, 2)
+    h = _act16(x, bn_in).permute(0, 3, 1, 2)
+    x, dy = _f(x), _f(dy)
     w0 = _ref_weight(torch.zeros(g.taps, g.Cin, g.Cout, dtype=x.dtype, device=x.device), g).requires_grad_(True)
     with torch.enable_grad():
         y = _conv_nchw(h, w0, g)
@@ -133,14 +164,24 @@ def conv_wgrad(x, dy, g: Geom, bn_in=None, out=None):
 
 
 # ---- residual-block glue -----------------------------------------------------------------------
+def _store(y, dtype):
+    """(value as stored, tensor in the storage dtype)"""
+    if dtype == BF16:
+        y = _q16(y)
+    return y, y.to(dtype)
+
+
 def block_out_fwd(s, m, bn_s, a=RES_A, b=RES_B, out_stats=None):
+    dt = s.dtype
+    s, m = _f(s), _f(m)
     _, _, scale, shift = bn_coef(bn_s)
-    out = a * (s * scale + shift) + b * m
+    out, stored = _store(a * (s * scale + shift) + b * m, dt)
     _accum(out_stats, out)
-    return out
+    return stored
 
 
 def bn_bwd_reduce(g, s, bn_s, sums=None):
+    g, s = _f(g), _f(s)
     mean, rstd, _, _ = bn_coef(bn_s)
     sums = torch.zeros(2, s.shape[-1], dtype=torch.float64, device=s.device)
     g2 = g.reshape(-1, g.shape[-1])
@@ -161,11 +202,15 @@ def _bn_bwd(dy, x, bn, sums):
 
 
 def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False, want_colsum_ds=True, small=None):
+    dt = g.dtype
+    g, s = _f(g), _f(s)
     dm = b * g
     mm = _mask_mult(g, mask)
     if mm is not None:
         dm = dm * mm
     ds = a * _bn_bwd(g, s, bn_s, sums)
+    if dt == BF16:
+        dm, ds = _q16(dm), _q16(ds)
     dgamma = (a * sums[1]).float()
     dbeta = (a * sums[0]).float()
     c = g.shape[-1]
@@ -178,17 +223,21 @@ def block_out_bwd(g, s, bn_s, sums, mask, a=RES_A, b=RES_B, want_colsum_dm=False
             cdm = small[2].copy_(cdm)
         if cds is not None:
             cds = small[3].copy_(cds)
-    return dm.contiguous(), ds.contiguous(), dgamma, dbeta, cdm, cds
+    return dm.contiguous().to(dt), ds.contiguous().to(dt), dgamma, dbeta, cdm, cds
 
 
 def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=None, next_s=None, next_bn=None,
                  next_sums=None):
+    dt = x.dtype
+    dy, x, add, next_s = _f(dy), _f(x), _f(add), _f(next_s)
     dx = _bn_bwd(dy, x, bn, sums)
     mm = _mask_mult(dx, mask)
     if mm is not None:
         dx = dx * mm
     if add is not None:
         dx = dx + add
+    if dt == BF16:
+        dx = _q16(dx)
     cs = dx.reshape(-1, dx.shape[-1]).sum(0) if want_colsum else None
     dx = dx.contiguous()
     if next_s is not None:
@@ -198,7 +247,7 @@ def bn_bwd_apply(dy, x, bn, sums, mask=None, add=None, want_colsum=False, small=
         dgamma, dbeta = small[0].copy_(dgamma), small[1].copy_(dbeta)
         if cs is not None:
             cs = small[2].copy_(cs)
-    return dx, dgamma, dbeta, cs
+    return dx.to(dt), dgamma, dbeta, cs
 
 
 def bn_running_update(entries, momentum=0.1):
@@ -211,7 +260,7 @@ def bn_running_update(entries, momentum=0.1):
 
 
 def colsum(x):
-    return x.reshape(-1, x.shape[-1]).sum(0)
+    return _f(x).reshape(-1, x.shape[-1]).sum(0)
 
 
 # ---- latent space -------------------------------------------------------------------------------
@@ -312,11 +361,12 @@ def token_logprob_rows(logp, ids):
     return logp.gather(-1, idx.unsqueeze(-1)).squeeze(-1).sum(dim=1)
 
 
-def embedding_fwd(ids, table):
-    return table[ids.long()]
+def embedding_fwd(ids, table, out_dtype=None):
+    return table[ids.long()].to(out_dtype or torch.float32)
 
 
 def embedding_bwd(ids, gout, vocab, padding_idx=0):
+    gout = _f(gout)
     d = torch.zeros(vocab, gout.shape[-1], dtype=torch.float32, device=gout.device)
     flat = ids.reshape(-1).long()
     d.index_add_(0, flat, gout.reshape(-1, gout.shape[-1]))
