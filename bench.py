@@ -34,15 +34,22 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 CONFIGS = {
-    # name: (img_size, class_dim, DIM_img, per-GPU batch)
-    "c1": (64, 64, 64, 8),
-    "c2": (128, 128, 64, 64),
-    "c5": (256, 256, 64, 32),
-    "c2b256": (128, 128, 64, 256),   # config #3's batch at fp32 (there is no bf16 path)
+    # name: (img_size, class_dim, DIM_img, per-GPU batch, compute dtype)
+    "c1": (64, 64, 64, 8, "fp32"),
+    "c2": (128, 128, 64, 64, "fp32"),         # BASELINE config #2 (and #4 per GPU): the default / headline workload
+    "c3": (128, 128, 64, 256, "bf16"),        # BASELINE config #3
+    "c5": (256, 256, 64, 32, "bf16"),         # BASELINE config #5 (per GPU)
+    "c5f32": (256, 256, 64, 32, "fp32"),      # config #5's shape in fp32
+    "c2b256": (128, 128, 64, 256, "fp32"),    # config #3's batch in fp32
 }
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# conv/linear FLOPs per sample per train step (fwd + dgrad + wgrad)
-FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c5": 42.63e9, "c2b256": 13.58e9}
+# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" 157.3 TF; bf16 MFMA ~2.5 PF dense; HBM3E ~8 TB/s
+FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
+# conv/linear FLOPs per sample per train step (fwd + dgrad + wgrad) and algorithmic bytes per sample
+# (3 passes x (in + out) elements x element size)
+FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c3": 13.58e9, "c5": 42.63e9, "c5f32": 42.63e9, "c2b256": 13.58e9}
+BYTES_PER_SAMPLE = {"c3": 55.0e6, "c5": 193.0e6}
 
 
 def synthetic_batches(flags, n, device, seed):
@@ -77,6 +84,8 @@ def cpu_baseline(cfg_name, steps=3, threads=None):
             v.data.zero_()
     params = [v for v in sd.values() if v.is_floating_point() and v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-5)
+    # bounded sample: about 3 steps of the default workload's cost (~10-30 s of CPU work), at least one timed step
+    steps = max(1, min(steps, round(steps * FLOPS_PER_SAMPLE["c2"] * 64 / (FLOPS_PER_SAMPLE[cfg_name] * bsz))))
     times = []
     for i in range(steps + 1):
         batch, eps = R.synthetic_batch(cfg, bsz, seed=100 + i)
@@ -127,14 +136,14 @@ def main():
     from mimic_amd.parallel import GradAllReducer
     from mimic_amd.utils.experiment import HotPathExperiment, default_flags
 
-    size, cdim, dimg, bsz = CONFIGS[args.config]
+    size, cdim, dimg, bsz, cdtype = CONFIGS[args.config]
     torch.manual_seed(0)  # PyTorch-default-style init (the reference has no custom init), seed 0
     # lr: the reference's cluster config value (5e-4, mimic/configs/leomed_mimic_config.json:20).  profiles/
     # r02_loss_trajectory.txt holds the CPU oracle's and the HIP path's losses side by side for this workload at 1e-5
     # and 5e-4 (uniform-random synthetic data: large transient spikes at 5e-4 in BOTH).  Step cost does not depend on lr.
     lr = args.lr if args.lr is not None else 5e-4
     flags = default_flags(img_size=size, class_dim=cdim, DIM_img=dimg, batch_size=bsz, device=device,
-                          initial_learning_rate=lr)
+                          initial_learning_rate=lr, compute_dtype=cdtype)
     exp = HotPathExperiment(flags)
     exp.mm_vae.to(device)
     exp.mm_vae.train()
@@ -231,9 +240,10 @@ def main():
         torch.cuda.synchronize()
         prof = ops.prof_collect()
         ops.prof_enable(False)
-        name, (n, ms, fl) = max(prof.items(), key=lambda kv: kv[1][1])
+        name, (n, ms, fl, by) = max(prof.items(), key=lambda kv: kv[1][1])
         all_ms = sum(v[1] for v in prof.values())
         all_fl = sum(v[2] for v in prof.values())
+        all_by = sum(v[3] for v in prof.values())
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
             with open(os.path.join(REPO, "profiles", "latest_pmc_hbm.json")) as f:
@@ -243,7 +253,22 @@ def main():
                 traffic = hit["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        if n:
+        if n and cdtype == "bf16":
+            # bf16 configs are HBM-bound by arithmetic intensity (C3 247, C5 221 FLOP/B against
+            # a ridge of ~312): the dominant kernel is priced against the HBM roofline with its ALGORITHMIC bytes (one
+            # read of the input activation + one write of the result per launch); its MFMA rate rides along
+            gbs = by / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
+                        "bytes_per_launch": by / n, "flops_per_launch": fl / n,
+                        "mfma_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                        "mfma_frac_of_bf16_peak": round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "all_gemm_kernels": {"ms_per_step": round(all_ms / nprof, 3),
+                                             "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
+                                             "algorithmic_gbs": round(all_by / (all_ms * 1e-3) / 1e9, 1),
+                                             "per_kernel_ms_per_step": {k: round(v[1] / nprof, 3) for k, v in prof.items()}}}
+        elif n:
             achieved = fl / (ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -263,16 +288,24 @@ def main():
         line = {
             "metric": "samples/sec", "value": round(value, 2), "unit": "samples/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if cdtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: MoPoE joint-ELBO train step, 3 modalities "
                                    f"(PA+Lateral+text) {size}x{size}, class_dim {cdim}, DIM_img {dimg}, DIM_text 128, "
-                                   f"vocab 3517, batch {bsz}/GPU, fp32, BatchNorm batch stats + dropout, Adam",
+                                   f"vocab 3517, batch {bsz}/GPU, "
+                                   + ("bf16 storage + bf16 MFMA with fp32 accumulation (fp32 statistics, latent kernel, "
+                                      "likelihoods, master weights, Adam)" if cdtype == "bf16" else "fp32")
+                                   + ", BatchNorm batch stats + dropout, Adam",
                        "global_batch": bsz * world, "parallelism": f"dp{world}",
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),
                        "host_enqueue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
                        "model_tflops": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12, 2),
-                       "model_frac_of_fp32_mfma_peak": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12
-                                                             / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                       ("model_frac_of_bf16_mfma_peak" if cdtype == "bf16" else "model_frac_of_fp32_mfma_peak"):
+                           round(FLOPS_PER_SAMPLE[args.config] * value / 1e12
+                                 / ((BF16_MFMA_PEAK_TFLOPS if cdtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * world), 4),
+                       **({"model_algorithmic_gbs": round(BYTES_PER_SAMPLE[args.config] * value / 1e9, 1),
+                           "model_frac_of_hbm_peak": round(BYTES_PER_SAMPLE[args.config] * value / 1e9 / (HBM_PEAK_GBS * world), 4)}
+                          if args.config in BYTES_PER_SAMPLE else {}),
                        "last_total_loss": scalars.get("total_loss"), "lr": lr},
             "roofline": roofline, "cpu_baseline": cpu,
         }

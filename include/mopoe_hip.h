@@ -302,8 +302,9 @@ int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtab
 /* ---- profiling support for bench.py ------------------------------------------------------------------
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch
  * stream.  mopoe_prof_collect synchronises those events and fills, per kernel instantiation (arrays of
- * MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms) and their summed algorithmic FLOPs
- * since the last collect.  Kinds (the host mirror turns them into the template names rocprofv3 prints):
+ * MOPOE_PROF_KINDS entries), the number of launches, their summed duration (ms), their summed algorithmic FLOPs and
+ * their summed algorithmic bytes (one read of the input activation + one write of the result; stated by the
+ * bf16 family, 0 elsewhere) since the last collect.  Kinds (the host mirror turns them into the template names rocprofv3 prints):
  *   0..31  gather_gemm_kernel, vector path: tile * 4 + spec (tile as in mopoe_conv_plan; spec 0 = run-time modes,
  *          1 forward, 2 forward with BN+ReLU on the operand, 3 input gradient)
  *   32..34 gather_gemm_kernel, scalar path: 128x128, 256x64, 64x64
@@ -314,7 +315,7 @@ int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtab
  *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
 #define MOPOE_PROF_KINDS 80
 int mopoe_prof_enable(int32_t on);
-int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops);
+int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes /* may be NULL */);
 
 #ifdef __cplusplus
 }

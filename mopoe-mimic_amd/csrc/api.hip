@@ -31,7 +31,7 @@ int check_launch(const char* what) {
 // ---- profiling ------------------------------------------------------------------------------------------
 struct ProfRec {
   hipEvent_t start, stop;
-  double flops;
+  double flops, bytes;
   int kind;
 };
 static std::mutex g_prof_mu;
@@ -39,18 +39,20 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_pool;   // created lazily, reused
 static size_t g_prof_used = 0;
 
-ProfScope::ProfScope(hipStream_t s, double flops, int kind) : stream(s), slot(-1) {
+ProfScope::ProfScope(hipStream_t s, double flops, int kind, double bytes) : stream(s), slot(-1) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_used == g_prof_pool.size()) {
     ProfRec r;
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
     r.flops = 0;
+    r.bytes = 0;
     r.kind = 0;
     g_prof_pool.push_back(r);
   }
   slot = (int)g_prof_used++;
   g_prof_pool[slot].flops = flops;
+  g_prof_pool[slot].bytes = bytes;
   g_prof_pool[slot].kind = kind;
   (void)hipEventRecord(g_prof_pool[slot].start, stream);
 }
@@ -76,9 +78,9 @@ extern "C" int mopoe_prof_enable(int32_t on) {
   return MOPOE_OK;
 }
 
-extern "C" int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops) {
+extern "C" int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int k = 0; k < PROF_NKINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_flops[k] = 0; }
+  for (int k = 0; k < PROF_NKINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_flops[k] = 0; if (total_bytes) total_bytes[k] = 0; }
   for (size_t i = 0; i < g_prof_used; ++i) {
     if (hipEventSynchronize(g_prof_pool[i].stop) != hipSuccess) { set_error("prof_collect: event sync failed"); return MOPOE_ERR_LAUNCH; }
     float t = 0;
@@ -87,6 +89,7 @@ extern "C" int mopoe_prof_collect(int64_t* launches, double* total_ms, double* t
     launches[k] += 1;
     total_ms[k] += t;
     total_flops[k] += g_prof_pool[i].flops;
+    if (total_bytes) total_bytes[k] += g_prof_pool[i].bytes;
   }
   g_prof_used = 0;
   return MOPOE_OK;

@@ -89,7 +89,9 @@ enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_W
 struct ProfScope {
   hipStream_t stream;
   int slot;
-  ProfScope(hipStream_t s, double flops, int kind);
+  // flops / bytes: the launch's ALGORITHMIC work (one read of the input activation + one write of the
+  // output per pass; bytes = 0 where not stated)
+  ProfScope(hipStream_t s, double flops, int kind, double bytes = 0.0);
   ~ProfScope();
 };
 

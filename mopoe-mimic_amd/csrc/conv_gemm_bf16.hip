@@ -688,7 +688,8 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
     const int spec = w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1);
-    ProfScope prof(stream, flops, PROF_BF16_GATHER + cfg * 3 + (spec - 1));
+    const double abytes = (double)xb + (double)a.rows_total * Cn * (out_f32 ? 4.0 : 2.0);
+    ProfScope prof(stream, flops, PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
 #define MOPOE_LAUNCH_H(BM_, BN_, WM_, WN_)                                                                                          \
   do {                                                                                                                            \
@@ -787,7 +788,7 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   const bool xf = a.bn_in.mode != 0;
-  ProfScope prof(stream, flops, PROF_BF16_WGRAD + (big ? 0 : 2) + (xf ? 1 : 0));
+  ProfScope prof(stream, flops, PROF_BF16_WGRAD + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
   dim3 grid(nI * nJ, taps, (unsigned)split);
 #define MOPOE_LAUNCH_WH(T_)                                                                                              \
   do {                                                                                                                 \

@@ -823,8 +823,8 @@ PROF_KINDS = _prof_kind_names()
 
 
 def prof_collect():
-    """-> {kernel kind: (launches, total ms, total algorithmic flops)} since the last collect"""
+    """-> {kernel kind: (launches, total ms, total algorithmic flops, total algorithmic bytes)} since the last collect"""
     k = len(PROF_KINDS)
-    n, ms, fl = (C.c_int64 * k)(), (C.c_double * k)(), (C.c_double * k)()
-    _check(lib().mopoe_prof_collect(n, ms, fl))
-    return {name: (n[i], ms[i], fl[i]) for i, name in enumerate(PROF_KINDS) if name is not None and n[i] > 0}
+    n, ms, fl, by = (C.c_int64 * k)(), (C.c_double * k)(), (C.c_double * k)(), (C.c_double * k)()
+    _check(lib().mopoe_prof_collect(n, ms, fl, by))
+    return {name: (n[i], ms[i], fl[i], by[i]) for i, name in enumerate(PROF_KINDS) if name is not None and n[i] > 0}
