@@ -102,10 +102,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   static_assert(B_PER_THR >= 1, "B tile");
   constexpr int B_ELEMS = w_nk ? BN * BNK_LD : BKH * BKN_LD;
 
-  __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * A_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][B_ELEMS];
+  // epilogue staging: each wave transposes its accumulators through a private [32 rows][WN + 4] fp32 patch, so that the
+  // result leaves the chip row-major in 16-byte pieces (and the BN/ReLU operand, the dropout mask and the bias arrive the
+  // same way); the patches overlay the operand tiles, which are dead by then
+  constexpr int STG_LD = WN + 4;
+  constexpr int A_BYTES = 2 * BM * A_LD * 2, B_BYTES = 2 * B_ELEMS * 2;
+  constexpr int STG_BYTES = (NT / 64) * 32 * STG_LD * 4;
+  constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > STG_BYTES ? (A_BYTES + B_BYTES) : STG_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   __shared__ __attribute__((aligned(16))) float bnS[xform ? MAX_BN_C : 4];
   __shared__ __attribute__((aligned(16))) float bnT[xform ? MAX_BN_C : 4];
+  __shared__ __attribute__((aligned(16))) float epi[5][BN];   // per output column: mean, rstd, scale, shift (relu_bn), bias
+  bf16_t* const As0 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* const Bs0 = reinterpret_cast<bf16_t*>(smem + A_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -141,16 +150,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   const bool do_relu_bn = a.relu_bn.mode != 0;
   const int hw = a.Hq * a.Wq;
 
-  float cbias[TJ], s1[TJ], s2[TJ];
-  BnC rbc[TJ];
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int n = n0 + wn * WN + j * 32 + l31;
-    s1[j] = s2[j] = 0.f;
-    cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
-    rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
-    if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+  // epilogue constants per output column of this block (zero for columns past Cn / for raw partial sums)
+  for (int c = tid; c < BN; c += NT) {
+    const int n = n0 + c;
+    BnC k = BnC{0.f, 0.f, 0.f, 0.f};
+    if (n < a.Cn && do_relu_bn && !a.partial) k = bn_coef(a.relu_bn, n);
+    epi[0][c] = k.mean; epi[1][c] = k.rstd; epi[2][c] = k.scale; epi[3][c] = k.shift;
+    epi[4][c] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
   }
+  __syncthreads();
+  // row-major epilogue: LPR lanes share one output row, each owns 8 consecutive columns (one 16-byte bf16 piece)
+  constexpr int LPR = WN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;
+  const int c8 = lane % LPR, rsub = lane / LPR;
+  const int ecol = wn * WN + c8 * 8;             // first of this lane's columns within the block tile
+  const int ncol = n0 + ecol;
+  const bool ncol_ok = ncol < a.Cn;              // (Cn % 8 == 0: the 8 columns are valid together)
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  float* const stg = reinterpret_cast<float*>(smem) + wave * 32 * STG_LD;
 
   // weight operand: per-thread byte offsets are fixed for the whole kernel, the K / tap advance is the scalar offset
   unsigned voffB[B_PER_THR];
@@ -231,16 +249,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
         const int r = trow + i * (NT / 4);
         uint4 v = ra[i];
         if (xform) v = bn_relu8(v, psc0, psc1, psh0, psh1, pend_ok[i]);
-        *reinterpret_cast<uint4*>(&As[buf][r * A_LD + kq * 8]) = v;
+        *reinterpret_cast<uint4*>(&As0[buf * BM * A_LD + r * A_LD + kq * 8]) = v;
       }
 #pragma unroll
       for (int i = 0; i < B_PER_THR; ++i) {
         if (w_nk) {
           const int r = trow + i * (NT / 4);
-          *reinterpret_cast<uint4*>(&Bs[buf][r * BNK_LD + kq * 8]) = rb[i];
+          *reinterpret_cast<uint4*>(&Bs0[buf * B_ELEMS + r * BNK_LD + kq * 8]) = rb[i];
         } else {
           const int p = tid + i * NT;
-          *reinterpret_cast<uint4*>(&Bs[buf][(p / N8) * BKN_LD + (p % N8) * 8]) = rb[i];
+          *reinterpret_cast<uint4*>(&Bs0[buf * B_ELEMS + (p / N8) * BKN_LD + (p % N8) * 8]) = rb[i];
         }
       }
     };
@@ -270,11 +288,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
         bf16x8 av[TI], bv[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
-          av[i] = *reinterpret_cast<const bf16x8*>(&As[cur][(wm * WM + i * 32 + l31) * A_LD + s * 16 + lhi * 8]);
+          av[i] = *reinterpret_cast<const bf16x8*>(&As0[cur * BM * A_LD + (wm * WM + i * 32 + l31) * A_LD + s * 16 + lhi * 8]);
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-          if (w_nk) bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][(wn * WN + j * 32 + l31) * BNK_LD + s * 16 + lhi * 8]);
-          else bv[j] = tr_frag<BKN_LD>(&Bs[cur][0], s * 16, wn * WN + j * 32, lane);
+          if (w_nk) bv[j] = *reinterpret_cast<const bf16x8*>(&Bs0[cur * B_ELEMS + (wn * WN + j * 32 + l31) * BNK_LD + s * 16 + lhi * 8]);
+          else bv[j] = tr_frag<BKN_LD>(&Bs0[cur * B_ELEMS], s * 16, wn * WN + j * 32, lane);
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -292,90 +310,118 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
     }
     if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
-    // ---- epilogue of this M tile: 32x32 accumulator layout row = (r & 3) + 8 (r >> 2) + 4 lhi, column = l31 ----------
+    // ---- epilogue of this M tile ------------------------------------------------------------------------------------
+    // accumulators (32x32 layout: row = (r & 3) + 8 (r >> 2) + 4 lhi, column = l31) -> this wave's staging patch -> rows
     bf16_t* __restrict__ Yh = reinterpret_cast<bf16_t*>(a.Y);
     float* __restrict__ Yf = reinterpret_cast<float*>(a.Y);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        long yrows[4];
-        const float* mrows[4];
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const long m = m0 + wm * WM + i * 32 + r4 + 8 * rg + 4 * lhi;
-          yrows[r4] = -1;
-          mrows[r4] = nullptr;
-          if (m < a.rows_per_phase) {
-            const unsigned mu = (unsigned)m;
-            const unsigned nn = mu / (unsigned)hw;
-            if (a.form == 0) {
-              yrows[r4] = m;
-            } else {
-              const unsigned rem = mu - nn * (unsigned)hw;
-              const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
-              yrows[r4] = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
-            }
-            if (a.mask.kind == 1) mrows[r4] = a.mask.mask + (long)nn * a.Cn;
-            else if (a.mask.kind == 2) mrows[r4] = a.mask.mask + yrows[r4] * a.Cn;
+        for (int r = 0; r < 16; ++r)
+          stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * STG_LD + j * 32 + l31] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the reads below see the patch
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int rr = p * RPP + rsub;
+        const float4 q0 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8]);
+        const float4 q1 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8 + 4]);
+        const long m = m0 + wm * WM + i * 32 + rr;
+        if (m >= a.rows_per_phase || !ncol_ok) continue;
+        const unsigned mu = (unsigned)m;
+        const unsigned nn = mu / (unsigned)hw;
+        long yrow = m;
+        if (a.form != 0) {
+          const unsigned rem = mu - nn * (unsigned)hw;
+          const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
+          yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+        }
+        float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (a.partial) {   // split reduction: raw partial sums, finished by splitk_epilogue_bf16_kernel
+          float* dst = a.partial + ((long)split * a.rows_total + yrow) * a.Cn + ncol;
+          *reinterpret_cast<float4*>(dst) = q0;
+          *reinterpret_cast<float4*>(dst + 4) = q1;
+          continue;
+        }
+        {
+          const float4 b0 = *reinterpret_cast<const float4*>(&epi[4][ecol]), b1 = *reinterpret_cast<const float4*>(&epi[4][ecol + 4]);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (a.mask.kind != 0) {
+          const float* mrow = a.mask.kind == 1 ? a.mask.mask + (long)nn * a.Cn + ncol : a.mask.mask + yrow * a.Cn + ncol;
+          const float4 k0 = *reinterpret_cast<const float4*>(mrow), k1 = *reinterpret_cast<const float4*>(mrow + 4);
+          v[0] *= k0.x; v[1] *= k0.y; v[2] *= k0.z; v[3] *= k0.w; v[4] *= k1.x; v[5] *= k1.y; v[6] *= k1.z; v[7] *= k1.w;
+        }
+        if (do_relu_bn) {
+          const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
+          const float xi[8] = {bf16_lo(xu.x), bf16_hi(xu.x), bf16_lo(xu.y), bf16_hi(xu.y),
+                               bf16_lo(xu.z), bf16_hi(xu.z), bf16_lo(xu.w), bf16_hi(xu.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = (fmaf(xi[e], epi[2][ecol + e], epi[3][ecol + e]) > 0.f) ? v[e] : 0.f;
+            if (!a.out_f32) x = round_bf16(x);
+            v[e] = x;
+            s1[e] += x;
+            s2[e] += x * ((xi[e] - epi[0][ecol + e]) * epi[1][ecol + e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (!a.out_f32) x = round_bf16(x);
+            v[e] = x;
+            s1[e] += x;
+            s2[e] += x * x;
           }
         }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const int n = n0 + wn * WN + j * 32 + l31;
-          const bool nok = n < a.Cn;
-          float v[4];
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const long yrow = yrows[r4];
-            const int r = rg * 4 + r4;
-            float x = acc[i][j][r];
-            if (a.partial) {   // split reduction: raw partial sums, finished by splitk_epilogue_bf16_kernel
-              if (yrow >= 0 && nok) a.partial[((long)split * a.rows_total + yrow) * a.Cn + n] = x;
-              v[r4] = 0.f;
-              continue;
-            }
-            x += cbias[j];
-            if (mrows[r4] && nok) x *= mrows[r4][n];
-            if (do_relu_bn) {
-              float xi = 0.f;
-              if (yrow >= 0 && nok) xi = bf16_to_f32(a.xin[yrow * a.ldy + n]);
-              x = (fmaf(xi, rbc[j].scale, rbc[j].shift) > 0.f) ? x : 0.f;
-              if (!a.out_f32) x = round_bf16(x);
-              if (yrow >= 0 && nok) { s1[j] += x; s2[j] += x * ((xi - rbc[j].mean) * rbc[j].rstd); }
-            } else {
-              if (!a.out_f32) x = round_bf16(x);
-              if (yrow >= 0 && nok) { s1[j] += x; s2[j] += x * x; }
-            }
-            v[r4] = x;
-          }
-          if (a.partial) continue;
-          if (a.out_f32) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              if (yrows[r4] >= 0 && nok) Yf[yrows[r4] * a.ldy + n] = v[r4];
-          } else {
-            // bf16 stores in pairs: lanes l (even column n) and l+1 hold columns n, n+1 of the same four rows; the even
-            // lane takes rows 0 and 2 of the group, the odd lane rows 1 and 3 -> every store is a 4-byte (n, n+1) pair.
-            // (Cn is even, so a valid even column has a valid right neighbour.)
-            const bool odd = lane & 1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float mine = odd ? v[2 * h + 1] : v[2 * h];
-              const float send = odd ? v[2 * h] : v[2 * h + 1];
-              const float recv = __shfl_xor(send, 1, 64);
-              const long yrow = odd ? yrows[2 * h + 1] : yrows[2 * h];
-              const unsigned packed = odd ? pack_bf16(recv, mine) : pack_bf16(mine, recv);
-              const int nn = odd ? n - 1 : n;
-              if (yrow >= 0 && nok) *reinterpret_cast<unsigned*>(&Yh[yrow * a.ldy + nn]) = packed;
-            }
-          }
+        if (a.out_f32) {
+          float* dst = Yf + yrow * a.ldy + ncol;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(Yh + yrow * a.ldy + ncol) =
+              make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         }
+      }
+      __builtin_amdgcn_wave_barrier();   // the next patch overwrites this one
+    }
+    __syncthreads();   // the staging patches overlay the operand tiles of the next M tile
+  }
+
+  // ---- column statistics: lanes -> wave -> block -> one atomic per column per block ------------------------------------
+  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
+  if (sums && !a.partial) {
+    float* cs = reinterpret_cast<float*>(smem);          // [2][waves][WN] (the staging area is free again)
+    constexpr int NW = NT / 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    }
+    if (rsub == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        cs[(0 * NW + wave) * WN + c8 * 8 + e] = s1[e];
+        cs[(1 * NW + wave) * WN + c8 * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int wnc = c / WN, cc = c - wnc * WN;
+      const int n = n0 + c;
+      if (n < a.Cn) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) { t1 += cs[(0 * NW + w * WGN + wnc) * WN + cc]; t2 += cs[(1 * NW + w * WGN + wnc) * WN + cc]; }
+        atomic_add_f64(sums + n, (double)t1);
+        atomic_add_f64(sums + a.Cn + n, (double)t2);
       }
     }
   }
-
-#include "gemm_colstats.inc"
 }
 
 // ---- split reduction epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums --------

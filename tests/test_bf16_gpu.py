@@ -11,6 +11,7 @@
 """
 import math
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -35,11 +36,11 @@ def _log(msg):
         f.write(msg + "\n")
 
 
-def check16(name, got, ref):
+def check16(name, got, ref, atol_rel=2e-4):
     """bf16 result: within one rounding step of the reference (+ fp32 accumulation noise on the tensor's scale)"""
     assert got.dtype == ref.dtype, (name, got.dtype, ref.dtype)
     if got.dtype == BF:
-        check(name, got.float(), ref.float(), rtol=1.01 * ULP, atol_rel=2e-4)
+        check(name, got.float(), ref.float(), rtol=1.01 * ULP, atol_rel=atol_rel)
     else:
         check(name, got, ref, rtol=2e-4, atol_rel=2e-4)
 
@@ -66,7 +67,7 @@ GEOMS16 = [
 
 
 def _conv_case(name, g: Geom, plan=None):
-    gen = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)   # (str hashes change per process)
     x = torch.randn(g.in_shape, generator=gen).to(BF)
     wp = (torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)).to(BF)
     bias = 0.1 * torch.randn(g.Cout, generator=gen)
@@ -84,7 +85,10 @@ def _conv_case(name, g: Geom, plan=None):
         y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref)
         st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
         y = ops.conv_fwd(xd, wd, g, bn_in=to_dev(bn), bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st)
-        check16(f"{name}/fwd_fused_bn{mode}", y, y_ref)
+        # (BN+ReLU'd operand elements are rounded to bf16 from an fma here and a multiply-add in the emulation: about one
+        # element in 4e4 rounds the other way, which moves an output by |w| times one operand step -- visible on outputs
+        # that are themselves near zero, hence the wider absolute term)
+        check16(f"{name}/fwd_fused_bn{mode}", y, y_ref, atol_rel=1.5e-3)
         # statistics are sums over the STORED values: a result that rounds the other way moves them by one step of one element
         check(f"{name}/fwd_fused_bn{mode}/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
     emask = Mask((torch.rand(g.out_shape, generator=gen) < 0.5).float() * 2, 2, rps_out)

@@ -7,6 +7,7 @@ in a different order, so results agree to ~1e-6 relative per accumulated term:
 """
 import math
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -88,7 +89,7 @@ GEOMS = [
 
 @pytest.mark.parametrize("name,g", GEOMS, ids=[n for n, _ in GEOMS])
 def test_conv_family(name, g: Geom):
-    gen = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)   # (str hashes change per process)
     x = torch.randn(g.in_shape, generator=gen)
     wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
     bias = 0.1 * torch.randn(g.Cout, generator=gen)

@@ -35,10 +35,12 @@ def flops(name, g):
 
 def main():
     cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
-    size, cdim, bsz = {"c2": (128, 128, 64), "c5": (256, 256, 32), "c1": (64, 64, 8)}[cfgname]
+    size, cdim, bsz, cdt = {"c2": (128, 128, 64, "fp32"), "c5f32": (256, 256, 32, "fp32"), "c1": (64, 64, 8, "fp32"),
+                            "c3": (128, 128, 256, "bf16"), "c5": (256, 256, 32, "bf16")}[cfgname]
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    flags = default_flags(img_size=size, class_dim=cdim, DIM_img=64, batch_size=bsz, device=dev, initial_learning_rate=1e-5)
+    flags = default_flags(img_size=size, class_dim=cdim, DIM_img=64, batch_size=bsz, device=dev, initial_learning_rate=1e-5,
+                          compute_dtype=cdt)
     exp = HotPathExperiment(flags); exp.mm_vae.to(dev).train(); exp.set_optimizer()
     b = {"PA": torch.rand(bsz, 1, size, size, device=dev), "Lateral": torch.rand(bsz, 1, size, size, device=dev),
          "text": torch.randint(0, 3517, (bsz, 128), device=dev).float()}
@@ -73,7 +75,11 @@ def main():
         flags = {"fwd": (k.get("bn_in") is not None, k.get("mask") is not None, k.get("out_stats") is not None),
                  "dgrad": (k.get("relu_bn") is not None, k.get("bwd_sums") is not None),
                  "wgrad": (k.get("bn_in") is not None,)}[kind]
-        plan = ops.plan_table().get((kind, g) + flags)
+        is16 = any(torch.is_tensor(x) and x.dtype == torch.bfloat16 for x in a) and min(g.Cin, g.Cout) > 1
+        if is16:
+            od = k.get("out_dtype") or next(x for x in a if torch.is_tensor(x)).dtype
+            flags = flags + ((od,) if kind != "wgrad" else ())
+        plan = ops.plan_table().get((kind + ("16" if is16 else ""), g) + flags)
         rows.append((us * len(lst) / 1e3, len(lst), us, name + fused + f" {plan}", g, flops(name, g)))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows); totfl = sum(r[5] * r[1] for r in rows)
