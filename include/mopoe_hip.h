@@ -87,7 +87,10 @@ typedef struct {
  * precedes every conv inside a residual block is fused into the operand load).
  * out_stats (optional) += {sum, sumsq} of the stored y per output channel.
  *
- * workspace: caller-owned scratch (mopoe_conv_workspace_bytes() is the recommended size; may be NULL/0).
+ * workspace: caller-owned scratch (mopoe_conv_workspace_bytes() is the recommended size; may be NULL/0).  Its first
+ * 64 KiB hold the arrival counters of in-kernel split reductions: they must be ZERO when a workspace is first handed
+ * over, every launch leaves them zero, and a workspace must not be shared by launches that may run concurrently
+ * (one workspace per stream).
  * Layers whose output grid cannot fill the chip split the tap x channel reduction across blocks, park
  * the partial sums there and finish (bias, mask, statistics) in a second small kernel. */
 size_t mopoe_conv_workspace_bytes(void);

@@ -981,6 +981,9 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
                          const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
                          const float* xin, double* bwd_sums, const mopoe_conv_plan* plan, void* ws, size_t ws_bytes,
                          hipStream_t stream) {
+  // the head of the workspace holds the arrival counters of the bf16 family's in-kernel split reductions (kept zero)
+  if (ws && ws_bytes > WS_COUNTER_BYTES) { ws = (char*)ws + WS_COUNTER_BYTES; ws_bytes -= WS_COUNTER_BYTES; }
+  else { ws = nullptr; ws_bytes = 0; }
   GemmArgs a;
   a.X = X; a.W = W; a.Y = Y; a.bias = bias;
   a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;

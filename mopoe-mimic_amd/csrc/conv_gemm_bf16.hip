@@ -49,7 +49,8 @@ struct GemmArgsH {
   double* bwd_sums;
   unsigned x_bytes, w_bytes;
   int nsplit;
-  float* partial;
+  float* partial;        // split reduction: [nsplit][rows_total][Cn] fp32 slabs (else nullptr)
+  int* counters;         // split reduction: one arrival counter per output tile, zero on entry, left zero
   long rows_total;
   int out_f32;
 };
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   __shared__ __attribute__((aligned(16))) float bnS[xform ? MAX_BN_C : 4];
   __shared__ __attribute__((aligned(16))) float bnT[xform ? MAX_BN_C : 4];
   __shared__ __attribute__((aligned(16))) float epi[5][BN];   // per output column: mean, rstd, scale, shift (relu_bn), bias
+  __shared__ int s_ticket;
+  bool was_last = false;   // split reduction: this block finished at least one tile (it then owns column statistics)
   bf16_t* const As0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* const Bs0 = reinterpret_cast<bf16_t*>(smem + A_BYTES);
 
@@ -150,13 +153,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   const bool do_relu_bn = a.relu_bn.mode != 0;
   const int hw = a.Hq * a.Wq;
 
-  // epilogue constants per output column of this block (zero for columns past Cn / for raw partial sums)
+  // epilogue constants per output column of this block (zero for columns past Cn)
   for (int c = tid; c < BN; c += NT) {
     const int n = n0 + c;
     BnC k = BnC{0.f, 0.f, 0.f, 0.f};
-    if (n < a.Cn && do_relu_bn && !a.partial) k = bn_coef(a.relu_bn, n);
+    if (n < a.Cn && do_relu_bn) k = bn_coef(a.relu_bn, n);
     epi[0][c] = k.mean; epi[1][c] = k.rstd; epi[2][c] = k.scale; epi[3][c] = k.shift;
-    epi[4][c] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
+    epi[4][c] = (n < a.Cn && a.bias) ? a.bias[n] : 0.f;
   }
   __syncthreads();
   // row-major epilogue: LPR lanes share one output row, each owns 8 consecutive columns (one 16-byte bf16 piece)
@@ -314,6 +317,62 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
     // accumulators (32x32 layout: row = (r & 3) + 8 (r >> 2) + 4 lhi, column = l31) -> this wave's staging patch -> rows
     bf16_t* __restrict__ Yh = reinterpret_cast<bf16_t*>(a.Y);
     float* __restrict__ Yf = reinterpret_cast<float*>(a.Y);
+    // output row of tile row (i, rr) of this wave; false if past the end
+    auto row_of = [&](int i, int rr, long& yrow, unsigned& nn) -> bool {
+      const long m = m0 + wm * WM + i * 32 + rr;
+      if (m >= a.rows_per_phase || !ncol_ok) return false;
+      const unsigned mu = (unsigned)m;
+      nn = mu / (unsigned)hw;
+      yrow = m;
+      if (a.form != 0) {
+        const unsigned rem = mu - nn * (unsigned)hw;
+        const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
+        yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
+      }
+      return true;
+    };
+    // bias, dropout mask, ReLU/BN-backward masking, rounding, statistics, store: 8 columns of one output row
+    auto finish_row = [&](float (&v)[8], long yrow, unsigned nn) {
+      {
+        const float4 b0 = *reinterpret_cast<const float4*>(&epi[4][ecol]), b1 = *reinterpret_cast<const float4*>(&epi[4][ecol + 4]);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (a.mask.kind != 0) {
+        const float* mrow = a.mask.kind == 1 ? a.mask.mask + (long)nn * a.Cn + ncol : a.mask.mask + yrow * a.Cn + ncol;
+        const float4 k0 = *reinterpret_cast<const float4*>(mrow), k1 = *reinterpret_cast<const float4*>(mrow + 4);
+        v[0] *= k0.x; v[1] *= k0.y; v[2] *= k0.z; v[3] *= k0.w; v[4] *= k1.x; v[5] *= k1.y; v[6] *= k1.z; v[7] *= k1.w;
+      }
+      if (do_relu_bn) {
+        const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
+        const float xi[8] = {bf16_lo(xu.x), bf16_hi(xu.x), bf16_lo(xu.y), bf16_hi(xu.y),
+                             bf16_lo(xu.z), bf16_hi(xu.z), bf16_lo(xu.w), bf16_hi(xu.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = (fmaf(xi[e], epi[2][ecol + e], epi[3][ecol + e]) > 0.f) ? v[e] : 0.f;
+          if (!a.out_f32) x = round_bf16(x);
+          v[e] = x;
+          s1[e] += x;
+          s2[e] += x * ((xi[e] - epi[0][ecol + e]) * epi[1][ecol + e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e];
+          if (!a.out_f32) x = round_bf16(x);
+          v[e] = x;
+          s1[e] += x;
+          s2[e] += x * x;
+        }
+      }
+      if (a.out_f32) {
+        float* dst = Yf + yrow * a.ldy + ncol;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(Yh + yrow * a.ldy + ncol) =
+            make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+      }
+    };
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -327,71 +386,69 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
         const int rr = p * RPP + rsub;
         const float4 q0 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8]);
         const float4 q1 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8 + 4]);
-        const long m = m0 + wm * WM + i * 32 + rr;
-        if (m >= a.rows_per_phase || !ncol_ok) continue;
-        const unsigned mu = (unsigned)m;
-        const unsigned nn = mu / (unsigned)hw;
-        long yrow = m;
-        if (a.form != 0) {
-          const unsigned rem = mu - nn * (unsigned)hw;
-          const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
-          yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
-        }
-        float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        if (a.partial) {   // split reduction: raw partial sums, finished by splitk_epilogue_bf16_kernel
+        long yrow;
+        unsigned nn;
+        if (!row_of(i, rr, yrow, nn)) continue;
+        if (a.partial) {   // split reduction: this block's slab of raw partial sums
           float* dst = a.partial + ((long)split * a.rows_total + yrow) * a.Cn + ncol;
           *reinterpret_cast<float4*>(dst) = q0;
           *reinterpret_cast<float4*>(dst + 4) = q1;
           continue;
         }
-        {
-          const float4 b0 = *reinterpret_cast<const float4*>(&epi[4][ecol]), b1 = *reinterpret_cast<const float4*>(&epi[4][ecol + 4]);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (a.mask.kind != 0) {
-          const float* mrow = a.mask.kind == 1 ? a.mask.mask + (long)nn * a.Cn + ncol : a.mask.mask + yrow * a.Cn + ncol;
-          const float4 k0 = *reinterpret_cast<const float4*>(mrow), k1 = *reinterpret_cast<const float4*>(mrow + 4);
-          v[0] *= k0.x; v[1] *= k0.y; v[2] *= k0.z; v[3] *= k0.w; v[4] *= k1.x; v[5] *= k1.y; v[6] *= k1.z; v[7] *= k1.w;
-        }
-        if (do_relu_bn) {
-          const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
-          const float xi[8] = {bf16_lo(xu.x), bf16_hi(xu.x), bf16_lo(xu.y), bf16_hi(xu.y),
-                               bf16_lo(xu.z), bf16_hi(xu.z), bf16_lo(xu.w), bf16_hi(xu.w)};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = (fmaf(xi[e], epi[2][ecol + e], epi[3][ecol + e]) > 0.f) ? v[e] : 0.f;
-            if (!a.out_f32) x = round_bf16(x);
-            v[e] = x;
-            s1[e] += x;
-            s2[e] += x * ((xi[e] - epi[0][ecol + e]) * epi[1][ecol + e]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            if (!a.out_f32) x = round_bf16(x);
-            v[e] = x;
-            s1[e] += x;
-            s2[e] += x * x;
-          }
-        }
-        if (a.out_f32) {
-          float* dst = Yf + yrow * a.ldy + ncol;
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          *reinterpret_cast<uint4*>(Yh + yrow * a.ldy + ncol) =
-              make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-        }
+        float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        finish_row(v, yrow, nn);
       }
       __builtin_amdgcn_wave_barrier();   // the next patch overwrites this one
+    }
+    if (a.partial) {
+      // ---- the split reduction finishes in the LAST-ARRIVING block of this tile (no second kernel) -----------------------
+      // publish: slab stores drained by every wave -> block barrier -> one agent-scope release + arrival ticket;
+      // the block that draws the last ticket acquires at agent scope, then all its waves sum the slabs with plain loads.
+      // Correct for any placement of a tile's blocks over CUs / XCDs (MI355X guide, split-K seam).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* cnt = a.counters + ((long)phase * gridDim.y + blockIdx.y) * nMt + mt;
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const bool last = s_ticket == a.nsplit - 1;   // block-uniform
+      if (last) {
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *cnt = 0;                                   // left zero for the next launch that uses this workspace
+        }
+        __syncthreads();
+        was_last = true;
+        const long slab = a.rows_total * (long)a.Cn;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+          for (int p = 0; p < NPASS; ++p) {
+            long yrow;
+            unsigned nn;
+            if (!row_of(i, p * RPP + rsub, yrow, nn)) continue;
+            const float* src = a.partial + yrow * a.Cn + ncol;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+              const float4 q0 = *reinterpret_cast<const float4*>(src + sp * slab);
+              const float4 q1 = *reinterpret_cast<const float4*>(src + sp * slab + 4);
+              v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+            }
+            finish_row(v, yrow, nn);
+          }
+        }
+      }
     }
     __syncthreads();   // the staging patches overlay the operand tiles of the next M tile
   }
 
   // ---- column statistics: lanes -> wave -> block -> one atomic per column per block ------------------------------------
   double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
-  if (sums && !a.partial) {
+  if (sums && (!a.partial || was_last)) {   // (block-uniform)
     float* cs = reinterpret_cast<float*>(smem);          // [2][waves][WN] (the staging area is free again)
     constexpr int NW = NT / 64;
 #pragma unroll
@@ -420,52 +477,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
         atomic_add_f64(sums + n, (double)t1);
         atomic_add_f64(sums + a.Cn + n, (double)t2);
       }
-    }
-  }
-}
-
-// ---- split reduction epilogue: Y = mask * (sum_s partial[s] + bias), optional ReLU/BN-backward masking + sums --------
-__global__ __launch_bounds__(256) void splitk_epilogue_bf16_kernel(const GemmArgsH a) {
-  __shared__ float cs[2][4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + tx;
-  const bool nok = n < a.Cn;
-  const bool do_relu_bn = a.relu_bn.mode != 0;
-  const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
-  BnC rb = {0.f, 0.f, 0.f, 0.f};
-  if (nok && do_relu_bn) rb = bn_coef(a.relu_bn, n);
-  const long stride = a.rows_total * (long)a.Cn;
-  float s1 = 0.f, s2 = 0.f;
-  if (nok) {
-    for (long row = (long)blockIdx.y * 4 + ty; row < a.rows_total; row += (long)gridDim.y * 4) {
-      const float* p = a.partial + row * a.Cn + n;
-      float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < a.nsplit; ++s) acc4[s & 3] += p[(long)s * stride];
-      float x = bias + ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]));
-      if (a.mask.kind != 0) x *= mask_at(a.mask, row, n, a.Cn);
-      if (do_relu_bn) {
-        const float xi = bf16_to_f32(a.xin[row * a.ldy + n]);
-        x = (fmaf(xi, rb.scale, rb.shift) > 0.f) ? x : 0.f;
-        if (!a.out_f32) x = round_bf16(x);
-        s1 += x;
-        s2 += x * ((xi - rb.mean) * rb.rstd);
-      } else {
-        if (!a.out_f32) x = round_bf16(x);
-        s1 += x;
-        s2 += x * x;
-      }
-      if (a.out_f32) reinterpret_cast<float*>(a.Y)[row * a.ldy + n] = x;
-      else reinterpret_cast<bf16_t*>(a.Y)[row * a.ldy + n] = f32_to_bf16(x);
-    }
-  }
-  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
-  if (sums) {
-    cs[0][ty][tx] = s1;
-    cs[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty == 0 && nok) {
-      atomic_add_f64(sums + n, (double)((cs[0][0][tx] + cs[0][1][tx]) + (cs[0][2][tx] + cs[0][3][tx])));
-      atomic_add_f64(sums + a.Cn + n, (double)((cs[1][0][tx] + cs[1][1][tx]) + (cs[1][2][tx] + cs[1][3][tx])));
     }
   }
 }
@@ -693,7 +704,7 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   a.out_stats = out_stats;
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
-  a.nsplit = 1; a.partial = nullptr;
+  a.nsplit = 1; a.partial = nullptr; a.counters = nullptr;
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
   if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
   if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
@@ -716,17 +727,25 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
   const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
+  // workspace = [arrival counters: WS_COUNTER_BYTES, zero between launches][fp32 slabs]
+  const bool can_split = ws && ws_bytes > WS_COUNTER_BYTES && blocks <= (long)(WS_COUNTER_BYTES / sizeof(int));
+  const size_t slab_bytes = can_split ? ws_bytes - WS_COUNTER_BYTES : 0;
+  long ns = 1;
   if (plan && plan->split > 0) {
-    long ns = std::min<long>(plan->split, iters);
-    if (ns >= 2 && (!ws || (size_t)ns * per > ws_bytes)) {
-      set_error("bf16 conv plan: split %ld needs %zu workspace bytes (have %zu)", ns, (size_t)ns * per, ws ? ws_bytes : (size_t)0);
+    ns = std::min<long>(plan->split, iters);
+    if (ns >= 2 && (!can_split || (size_t)ns * per > slab_bytes)) {
+      set_error("bf16 conv plan: split %ld needs %zu workspace bytes (have %zu) and at most %zu output tiles (have %ld)", ns,
+                (size_t)ns * per + WS_COUNTER_BYTES, ws ? ws_bytes : (size_t)0, WS_COUNTER_BYTES / sizeof(int), blocks);
       return MOPOE_ERR_ARG;
     }
-    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
-  } else if (ws && blocks < 256 && iters >= 8) {
-    long ns = std::min<long>((512 + blocks - 1) / blocks, (long)iters / 4);
-    if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
-    if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
+  } else if (can_split && blocks < 256 && iters >= 8) {
+    ns = std::min<long>((512 + blocks - 1) / blocks, (long)iters / 4);
+    if ((size_t)ns * per > slab_bytes) ns = (long)(slab_bytes / per);
+  }
+  if (ns >= 2) {
+    a.nsplit = (int)ns;
+    a.counters = (int*)ws;
+    a.partial = (float*)((char*)ws + WS_COUNTER_BYTES);
   }
   const long persist = cfg == 3 ? 512 : 768;
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
@@ -750,11 +769,6 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
     else MOPOE_LAUNCH_H(64, 64, 2, 2);
 #undef MOPOE_LAUNCH_H
     if (int rc = check_launch("gather_gemm_bf16")) return rc;
-    if (a.partial) {
-      dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), 256));
-      hipLaunchKernelGGL(splitk_epilogue_bf16_kernel, eg, dim3(256), 0, stream, a);
-      if (int rc = check_launch("splitk_epilogue_bf16")) return rc;
-    }
   }
   return MOPOE_OK;
 }

@@ -23,6 +23,8 @@ constexpr int MAX_BN_C = 1024;
 // 2^31 rather than ~0 so that voffset + soffset cannot wrap whichever of the two the range check includes.
 constexpr unsigned OOB = 0x80000000u;
 constexpr size_t WS_RECOMMENDED = 64u << 20;
+// head of the conv workspace: one int arrival counter per output tile of a split reduction (zero between launches)
+constexpr size_t WS_COUNTER_BYTES = 64u << 10;
 
 // ---- which taps a block multiplies, and from where --------------------------------------------------------------
 // form 0: every tap, source pixel = output pixel * stride - pad + tap.  form 1 (sub-pixel phase `phase` of the big

@@ -212,7 +212,7 @@ def _workspace(device):
     if key not in _conv_ws:
         lib().mopoe_conv_workspace_bytes.restype = C.c_size_t
         nbytes = int(lib().mopoe_conv_workspace_bytes())
-        _conv_ws[key] = (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes)
+        _conv_ws[key] = (torch.zeros(nbytes, dtype=torch.uint8, device=device), nbytes)   # (arrival counters start at zero)
     return _conv_ws[key]
 
 
@@ -301,9 +301,13 @@ def _gather_shape(kind: str, g: Geom):
     return rows, g.sh * g.sw, max(1, (g.kh // g.sh) * (g.kw // g.sw)), ck, cn
 
 
+WS_COUNTER_BYTES = 64 << 10   # head of the workspace: arrival counters of in-kernel split reductions (header: workspace)
+
+
 def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
     if min(g.Cin, g.Cout) == 1:
         return {}   # image-side edge layers run on the streaming edge kernels: nothing to choose
+    ws_bytes -= WS_COUNTER_BYTES
     rows, nphase, taps, ck, cn = _gather_shape(kind, g)
     iters = taps * -(-ck // 16)
     per = rows * nphase * cn * 4
@@ -412,6 +416,7 @@ def _is16(t):
 
 
 def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int):
+    ws_bytes -= WS_COUNTER_BYTES
     rows, nphase, taps, ck, cn = _gather_shape(kind, g)
     iters = taps * (ck // 32)
     per = rows * nphase * cn * 4
