@@ -73,8 +73,24 @@ struct GemmArgs {
   unsigned x_bytes, w_bytes;   // sizes of X and W for the buffer descriptors (vector path)
   int nsplit;            // split-K factor (1 = none)
   float* partial;        // split-K: [nsplit][rows_total][Cn] raw partial sums (else nullptr)
+  int* counters;         // vector path: one arrival counter per output tile of a split reduction (zero on entry, left zero)
   long rows_total;       // N*Hy*Wy
 };
+
+// storage helpers of gemm_epilogue_rows.inc for this family: fp32 results and fp32 xin, rows of Cn floats; a lane's 8
+// columns are two float4 halves, the upper one may lie past Cn (Cn % 4 == 0 on the vector path)
+__device__ __forceinline__ float epi_round(const GemmArgs&, float x) { return x; }
+__device__ __forceinline__ void epi_xin8(const GemmArgs& a, long yrow, int ncol, bool ok_hi, float (&xi)[8]) {
+  const float* p = a.xin + yrow * a.Cn + ncol;
+  const float4 lo = *reinterpret_cast<const float4*>(p);
+  const float4 hi = ok_hi ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; xi[3] = lo.w; xi[4] = hi.x; xi[5] = hi.y; xi[6] = hi.z; xi[7] = hi.w;
+}
+__device__ __forceinline__ void epi_store8(const GemmArgs& a, long yrow, int ncol, bool ok_hi, const float (&v)[8]) {
+  float* dst = a.Y + yrow * a.Cn + ncol;
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  if (ok_hi) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
 
 
 // 16-byte buffer load with hardware bounds check: no branch, no exec masking, zero for off >= bytes
@@ -129,10 +145,21 @@ void gather_gemm_kernel(const GemmArgs a) {
   constexpr int B_PER_THR_KN = (GBK * N4 + NT - 1) / NT;
   constexpr int B_PER_THR = B_PER_THR_NK > B_PER_THR_KN ? B_PER_THR_NK : B_PER_THR_KN;
 
-  __shared__ __attribute__((aligned(16))) float As[2][GBK][A_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GBK][B_LD];
+  // operand tiles As[2][GBK][A_LD], Bs[2][GBK][B_LD]; the vector path's epilogue overlays them with one
+  // [32][WN + 4] fp32 staging patch per wave (gemm_epilogue_rows.inc)
+  constexpr int STG_LD = WN + 4;
+  constexpr int A_FLOATS = 2 * GBK * A_LD, B_FLOATS = 2 * GBK * B_LD;
+  constexpr int STG_FLOATS = VEC ? (NT / 64) * 32 * STG_LD : 0;
+  constexpr int SMEM_FLOATS = (A_FLOATS + B_FLOATS) > STG_FLOATS ? (A_FLOATS + B_FLOATS) : STG_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   __shared__ __attribute__((aligned(16))) float bnS[MAX_BN_C];
   __shared__ __attribute__((aligned(16))) float bnT[MAX_BN_C];
+  __shared__ __attribute__((aligned(16))) float epi[5][VEC ? BN : 4];   // per block column: mean, rstd, scale, shift (relu_bn), bias
+  __shared__ int s_ticket;
+  float* const As0 = smem;
+  float* const Bs0 = smem + A_FLOATS;
+#define AS_(buf, k, r) As0[((buf) * GBK + (k)) * A_LD + (r)]
+#define BS_(buf, k, r) Bs0[((buf) * GBK + (k)) * B_LD + (r)]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -175,15 +202,35 @@ void gather_gemm_kernel(const GemmArgs a) {
   const int hw = a.Hq * a.Wq;
 
   // per-column epilogue constants and running column sums (persist across this block's M tiles)
-  float cbias[TJ], s1[TJ], s2[TJ];
+  static_assert(TJ <= 8, "column sums live in s1[8] / s2[8] on both epilogue paths");
+  float cbias[TJ], s1[8], s2[8];
   BnC rbc[TJ];
 #pragma unroll
-  for (int j = 0; j < TJ; ++j) {
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {   // scalar path: per-column constants of the MFMA-layout epilogue (gemm_epilogue.inc)
     const int n = n0 + wn * WN + j * 32 + l31;
-    s1[j] = s2[j] = 0.f;
-    cbias[j] = (n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
+    cbias[j] = (!VEC && n < a.Cn && a.bias && !a.partial) ? a.bias[n] : 0.f;
     rbc[j] = BnC{0.f, 0.f, 0.f, 0.f};
-    if (n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+    if (!VEC && n < a.Cn && do_relu_bn && !a.partial) rbc[j] = bn_coef(a.relu_bn, n);
+  }
+  // vector path: row-major epilogue (gemm_epilogue_rows.inc): LPR lanes share one output row, each owns 8 columns
+  constexpr int E_LPR = WN / 8, E_RPP = 64 / E_LPR, E_NPASS = 32 / E_RPP;
+  const int c8 = lane % E_LPR, rsub = lane / E_LPR;
+  const int ecol = wn * WN + c8 * 8;
+  const int ncol = n0 + ecol;
+  const bool ok_lo = ncol < a.Cn, ok_hi = ncol + 4 < a.Cn;
+  float* const stg = smem + wave * 32 * STG_LD;
+  bool was_last = false;
+  if constexpr (VEC) {
+    for (int c = tid; c < BN; c += NT) {
+      const int n = n0 + c;
+      BnC k = BnC{0.f, 0.f, 0.f, 0.f};
+      if (n < a.Cn && do_relu_bn) k = bn_coef(a.relu_bn, n);
+      epi[0][c] = k.mean; epi[1][c] = k.rstd; epi[2][c] = k.scale; epi[3][c] = k.shift;
+      epi[4][c] = (n < a.Cn && a.bias) ? a.bias[n] : 0.f;
+    }
+    __syncthreads();
   }
 
   // fast operand addressing (vector path, Ck a multiple of the K chunk): per-thread byte offsets are fixed per tap
@@ -356,26 +403,26 @@ void gather_gemm_kernel(const GemmArgs a) {
           ra[i].z = ok ? fmaxf(fmaf(ra[i].z, pend_sc.z, pend_sh.z), 0.f) : 0.f;
           ra[i].w = ok ? fmaxf(fmaf(ra[i].w, pend_sc.w, pend_sh.w), 0.f) : 0.f;
         }
-        As[buf][kq * 4 + 0][r] = ra[i].x;
-        As[buf][kq * 4 + 1][r] = ra[i].y;
-        As[buf][kq * 4 + 2][r] = ra[i].z;
-        As[buf][kq * 4 + 3][r] = ra[i].w;
+        AS_(buf, kq * 4 + 0, r) = ra[i].x;
+        AS_(buf, kq * 4 + 1, r) = ra[i].y;
+        AS_(buf, kq * 4 + 2, r) = ra[i].z;
+        AS_(buf, kq * 4 + 3, r) = ra[i].w;
       }
       if (w_nk == 0) {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_KN; ++i) {
           const int k = tid / N4 + i * (NT / N4);
-          if (k < GBK) *reinterpret_cast<float4*>(&Bs[buf][k][(tid % N4) * 4]) = rb[i];
+          if (k < GBK) *reinterpret_cast<float4*>(&BS_(buf, k, (tid % N4) * 4)) = rb[i];
         }
       } else {
 #pragma unroll
         for (int i = 0; i < B_PER_THR_NK; ++i) {
           const int r = trow + i * RPP;
           if (r >= BN) continue;
-          Bs[buf][kq * 4 + 0][r] = rb[i].x;
-          Bs[buf][kq * 4 + 1][r] = rb[i].y;
-          Bs[buf][kq * 4 + 2][r] = rb[i].z;
-          Bs[buf][kq * 4 + 3][r] = rb[i].w;
+          BS_(buf, kq * 4 + 0, r) = rb[i].x;
+          BS_(buf, kq * 4 + 1, r) = rb[i].y;
+          BS_(buf, kq * 4 + 2, r) = rb[i].z;
+          BS_(buf, kq * 4 + 3, r) = rb[i].w;
         }
       }
     };
@@ -411,9 +458,9 @@ void gather_gemm_kernel(const GemmArgs a) {
         const int k = kk * 2 + lhi;
         float av[TI], bv[TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) av[i] = As[cur][k][wm * WM + i * 32 + l31];
+        for (int i = 0; i < TI; ++i) av[i] = AS_(cur, k, wm * WM + i * 32 + l31);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) bv[j] = Bs[cur][k][wn * WN + j * 32 + l31];
+        for (int j = 0; j < TJ; ++j) bv[j] = BS_(cur, k, wn * WN + j * 32 + l31);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -433,10 +480,20 @@ void gather_gemm_kernel(const GemmArgs a) {
     }
     if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
+    if constexpr (VEC) {
+#include "gemm_epilogue_rows.inc"
+    } else {
 #include "gemm_epilogue.inc"
+    }
   }
 
+  if constexpr (VEC) {
+#include "gemm_colstats_rows.inc"
+  } else {
 #include "gemm_colstats.inc"
+  }
+#undef AS_
+#undef BS_
 }
 
 // =====================================================================================================
@@ -981,8 +1038,9 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
                          const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
                          const float* xin, double* bwd_sums, const mopoe_conv_plan* plan, void* ws, size_t ws_bytes,
                          hipStream_t stream) {
-  // the head of the workspace holds the arrival counters of the bf16 family's in-kernel split reductions (kept zero)
-  if (ws && ws_bytes > WS_COUNTER_BYTES) { ws = (char*)ws + WS_COUNTER_BYTES; ws_bytes -= WS_COUNTER_BYTES; }
+  // the head of the workspace holds the arrival counters of in-kernel split reductions (kept zero by the kernels)
+  int* counters = nullptr;
+  if (ws && ws_bytes > WS_COUNTER_BYTES) { counters = (int*)ws; ws = (char*)ws + WS_COUNTER_BYTES; ws_bytes -= WS_COUNTER_BYTES; }
   else { ws = nullptr; ws_bytes = 0; }
   GemmArgs a;
   a.X = X; a.W = W; a.Y = Y; a.bias = bias;
@@ -1003,7 +1061,9 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   const size_t xb = (size_t)g->N * a.Hx * a.Wx * Ck * sizeof(float);
   const size_t wb = (size_t)g->kh * g->kw * g->Cin * g->Cout * sizeof(float);
   // branch-free buffer loads need 16-byte alignment, channel counts that are multiples of 4 and < 2 GiB operands
-  const bool vec = a.vecA && a.vecB && xb < (1ull << 31) && wb < (1ull << 31);
+  // (the vector path's row-major epilogue moves the result, xin and the mask in float4 pieces: Cn % 4 == 0, aligned rows)
+  const bool vec = a.vecA && a.vecB && xb < (1ull << 31) && wb < (1ull << 31) && Cn % 4 == 0 && aligned16(Y) &&
+                   (!xin || aligned16(xin)) && (!mask || mask->kind == 0 || aligned16(mask->mask));
   a.x_bytes = (unsigned)std::min<size_t>(xb, 0x7fffffffu);
   a.w_bytes = (unsigned)std::min<size_t>(wb, 0x7fffffffu);
   mopoe_bn_ref none = {};
@@ -1013,7 +1073,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.out_stats = out_stats;
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
-  a.nsplit = 1; a.partial = nullptr;
+  a.nsplit = 1; a.partial = nullptr; a.counters = nullptr;
   static const bool dbg_nostats = getenv("MOPOE_DEBUG_NOSTATS") != nullptr;  // timing experiments only
   if (dbg_nostats) { a.out_stats = nullptr; a.bwd_sums = nullptr; }
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
@@ -1063,6 +1123,13 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if ((size_t)ns * per > ws_bytes) ns = (long)(ws_bytes / per);
     if (ns >= 2) { a.nsplit = (int)ns; a.partial = (float*)ws; }
   }
+  // vector path, LDS kernels: the reduction finishes in the tile's last-arriving block (gemm_epilogue_rows.inc); the
+  // scalar path and the LDS-free kernels park raw slabs for splitk_epilogue_kernel
+  const bool in_kernel_reduce = vec && cfg < 8;
+  if (a.partial && in_kernel_reduce) {
+    if (blocks > (long)(WS_COUNTER_BYTES / sizeof(int))) { set_error("conv: split reduction over %ld output tiles (at most %zu)", blocks, WS_COUNTER_BYTES / sizeof(int)); return MOPOE_ERR_ARG; }
+    a.counters = counters;
+  }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
   const long persist = cfg >= 8 ? 4096 : ((cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS);   // 4-wave blocks: 3 per CU
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
@@ -1110,7 +1177,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
 #undef MOPOE_LAUNCH_TILE
 #undef MOPOE_LAUNCH_DIRECT
     if (int rc = check_launch("gather_gemm")) return rc;
-    if (a.partial) {
+    if (a.partial && !in_kernel_reduce) {
       dim3 eg(ceil_div(Cn, 64), std::min<long>(ceil_div(a.rows_total, 4), EPI_MAX_BLOCKS_Y));
       hipLaunchKernelGGL(splitk_epilogue_kernel, eg, dim3(256), 0, stream, a);
       if (int rc = check_launch("splitk_epilogue")) return rc;

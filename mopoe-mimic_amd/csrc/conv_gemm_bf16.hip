@@ -55,6 +55,24 @@ struct GemmArgsH {
   int out_f32;
 };
 
+// storage helpers of gemm_epilogue_rows.inc for this family: bf16 (or, on request, fp32) results, bf16 xin
+__device__ __forceinline__ float epi_round(const GemmArgsH& a, float x) { return a.out_f32 ? x : round_bf16(x); }
+__device__ __forceinline__ void epi_xin8(const GemmArgsH& a, long yrow, int ncol, bool /*ok_hi*/, float (&xi)[8]) {
+  const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
+  xi[0] = bf16_lo(xu.x); xi[1] = bf16_hi(xu.x); xi[2] = bf16_lo(xu.y); xi[3] = bf16_hi(xu.y);
+  xi[4] = bf16_lo(xu.z); xi[5] = bf16_hi(xu.z); xi[6] = bf16_lo(xu.w); xi[7] = bf16_hi(xu.w);
+}
+__device__ __forceinline__ void epi_store8(const GemmArgsH& a, long yrow, int ncol, bool /*ok_hi*/, const float (&v)[8]) {
+  if (a.out_f32) {
+    float* dst = reinterpret_cast<float*>(a.Y) + yrow * a.ldy + ncol;
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + yrow * a.ldy + ncol) =
+        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  }
+}
+
 __device__ __forceinline__ uint4 bldq(__amdgpu_buffer_rsrc_t srd, unsigned byte_off, unsigned s_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, s_off, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -162,12 +180,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
     epi[4][c] = (n < a.Cn && a.bias) ? a.bias[n] : 0.f;
   }
   __syncthreads();
-  // row-major epilogue: LPR lanes share one output row, each owns 8 consecutive columns (one 16-byte bf16 piece)
-  constexpr int LPR = WN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;
-  const int c8 = lane % LPR, rsub = lane / LPR;
+  // row-major epilogue: E_LPR lanes share one output row, each owns 8 consecutive columns (one 16-byte bf16 piece)
+  constexpr int E_LPR = WN / 8, E_RPP = 64 / E_LPR, E_NPASS = 32 / E_RPP;
+  const int c8 = lane % E_LPR, rsub = lane / E_LPR;
   const int ecol = wn * WN + c8 * 8;             // first of this lane's columns within the block tile
   const int ncol = n0 + ecol;
-  const bool ncol_ok = ncol < a.Cn;              // (Cn % 8 == 0: the 8 columns are valid together)
+  const bool ok_lo = ncol < a.Cn, ok_hi = ok_lo;   // (Cn % 8 == 0: the 8 columns are valid together)
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -313,172 +331,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
     }
     if (it < total) chunk(it, std::integral_constant<int, 0>{});
 
-    // ---- epilogue of this M tile ------------------------------------------------------------------------------------
-    // accumulators (32x32 layout: row = (r & 3) + 8 (r >> 2) + 4 lhi, column = l31) -> this wave's staging patch -> rows
-    bf16_t* __restrict__ Yh = reinterpret_cast<bf16_t*>(a.Y);
-    float* __restrict__ Yf = reinterpret_cast<float*>(a.Y);
-    // output row of tile row (i, rr) of this wave; false if past the end
-    auto row_of = [&](int i, int rr, long& yrow, unsigned& nn) -> bool {
-      const long m = m0 + wm * WM + i * 32 + rr;
-      if (m >= a.rows_per_phase || !ncol_ok) return false;
-      const unsigned mu = (unsigned)m;
-      nn = mu / (unsigned)hw;
-      yrow = m;
-      if (a.form != 0) {
-        const unsigned rem = mu - nn * (unsigned)hw;
-        const unsigned py = rem / (unsigned)a.Wq, px = rem - py * (unsigned)a.Wq;
-        yrow = ((long)nn * a.Hy + (py * a.sh + phy)) * a.Wy + (px * a.sw + phx);
-      }
-      return true;
-    };
-    // bias, dropout mask, ReLU/BN-backward masking, rounding, statistics, store: 8 columns of one output row
-    auto finish_row = [&](float (&v)[8], long yrow, unsigned nn) {
-      {
-        const float4 b0 = *reinterpret_cast<const float4*>(&epi[4][ecol]), b1 = *reinterpret_cast<const float4*>(&epi[4][ecol + 4]);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (a.mask.kind != 0) {
-        const float* mrow = a.mask.kind == 1 ? a.mask.mask + (long)nn * a.Cn + ncol : a.mask.mask + yrow * a.Cn + ncol;
-        const float4 k0 = *reinterpret_cast<const float4*>(mrow), k1 = *reinterpret_cast<const float4*>(mrow + 4);
-        v[0] *= k0.x; v[1] *= k0.y; v[2] *= k0.z; v[3] *= k0.w; v[4] *= k1.x; v[5] *= k1.y; v[6] *= k1.z; v[7] *= k1.w;
-      }
-      if (do_relu_bn) {
-        const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
-        const float xi[8] = {bf16_lo(xu.x), bf16_hi(xu.x), bf16_lo(xu.y), bf16_hi(xu.y),
-                             bf16_lo(xu.z), bf16_hi(xu.z), bf16_lo(xu.w), bf16_hi(xu.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = (fmaf(xi[e], epi[2][ecol + e], epi[3][ecol + e]) > 0.f) ? v[e] : 0.f;
-          if (!a.out_f32) x = round_bf16(x);
-          v[e] = x;
-          s1[e] += x;
-          s2[e] += x * ((xi[e] - epi[0][ecol + e]) * epi[1][ecol + e]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e];
-          if (!a.out_f32) x = round_bf16(x);
-          v[e] = x;
-          s1[e] += x;
-          s2[e] += x * x;
-        }
-      }
-      if (a.out_f32) {
-        float* dst = Yf + yrow * a.ldy + ncol;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        *reinterpret_cast<uint4*>(Yh + yrow * a.ldy + ncol) =
-            make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * STG_LD + j * 32 + l31] = acc[i][j][r];
-      __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the reads below see the patch
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int rr = p * RPP + rsub;
-        const float4 q0 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8]);
-        const float4 q1 = *reinterpret_cast<const float4*>(&stg[rr * STG_LD + c8 * 8 + 4]);
-        long yrow;
-        unsigned nn;
-        if (!row_of(i, rr, yrow, nn)) continue;
-        if (a.partial) {   // split reduction: this block's slab of raw partial sums
-          float* dst = a.partial + ((long)split * a.rows_total + yrow) * a.Cn + ncol;
-          *reinterpret_cast<float4*>(dst) = q0;
-          *reinterpret_cast<float4*>(dst + 4) = q1;
-          continue;
-        }
-        float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        finish_row(v, yrow, nn);
-      }
-      __builtin_amdgcn_wave_barrier();   // the next patch overwrites this one
-    }
-    if (a.partial) {
-      // ---- the split reduction finishes in the LAST-ARRIVING block of this tile (no second kernel) -----------------------
-      // publish: slab stores drained by every wave -> block barrier -> one agent-scope release + arrival ticket;
-      // the block that draws the last ticket acquires at agent scope, then all its waves sum the slabs with plain loads.
-      // Correct for any placement of a tile's blocks over CUs / XCDs (MI355X guide, split-K seam).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* cnt = a.counters + ((long)phase * gridDim.y + blockIdx.y) * nMt + mt;
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      const bool last = s_ticket == a.nsplit - 1;   // block-uniform
-      if (last) {
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          *cnt = 0;                                   // left zero for the next launch that uses this workspace
-        }
-        __syncthreads();
-        was_last = true;
-        const long slab = a.rows_total * (long)a.Cn;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-#pragma unroll
-          for (int p = 0; p < NPASS; ++p) {
-            long yrow;
-            unsigned nn;
-            if (!row_of(i, p * RPP + rsub, yrow, nn)) continue;
-            const float* src = a.partial + yrow * a.Cn + ncol;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-              const float4 q0 = *reinterpret_cast<const float4*>(src + sp * slab);
-              const float4 q1 = *reinterpret_cast<const float4*>(src + sp * slab + 4);
-              v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
-            }
-            finish_row(v, yrow, nn);
-          }
-        }
-      }
-    }
-    __syncthreads();   // the staging patches overlay the operand tiles of the next M tile
+#include "gemm_epilogue_rows.inc"
   }
 
-  // ---- column statistics: lanes -> wave -> block -> one atomic per column per block ------------------------------------
-  double* sums = do_relu_bn ? a.bwd_sums : a.out_stats;
-  if (sums && (!a.partial || was_last)) {   // (block-uniform)
-    float* cs = reinterpret_cast<float*>(smem);          // [2][waves][WN] (the staging area is free again)
-    constexpr int NW = NT / 64;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-        s1[e] += __shfl_xor(s1[e], o, 64);
-        s2[e] += __shfl_xor(s2[e], o, 64);
-      }
-    }
-    if (rsub == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        cs[(0 * NW + wave) * WN + c8 * 8 + e] = s1[e];
-        cs[(1 * NW + wave) * WN + c8 * 8 + e] = s2[e];
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      const int wnc = c / WN, cc = c - wnc * WN;
-      const int n = n0 + c;
-      if (n < a.Cn) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WGM; ++w) { t1 += cs[(0 * NW + w * WGN + wnc) * WN + cc]; t2 += cs[(1 * NW + w * WGN + wnc) * WN + cc]; }
-        atomic_add_f64(sums + n, (double)t1);
-        atomic_add_f64(sums + a.Cn + n, (double)t2);
-      }
-    }
-  }
+#include "gemm_colstats_rows.inc"
 }
 
 // =====================================================================================================
