@@ -74,6 +74,7 @@ class MaskSource:
 WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
 FUSE_NEXT_REDUCE = os.environ.get("MOPOE_FUSE_NEXT_REDUCE", "1") != "0"
 LANES = os.environ.get("MOPOE_LANES", "0,1").split(",")   # 0 = weight gradients, 1 = projection-shortcut branch
+LANES_IN_CAPTURE = os.environ.get("MOPOE_LANES_IN_CAPTURE", "0") != "0"   # (tests/tools/capture_probe_torch.py)
 _side_streams = {}
 
 
@@ -92,11 +93,14 @@ class _WgradLane:
     backward), which is independent of the main conv1 -> conv2 chain until the residual mix."""
 
     def __init__(self, device, which=0):
-        # not while a hipGraph is being captured: lanes forked from the per-modality streams (themselves forked from
-        # the capture stream) make hipStreamEndCapture crash on ROCm 7.2; the graph gets its parallelism from the
-        # modality streams alone
+        # not while a hipGraph is being captured under the modality forks: a stream that waits, inside a capture, on an
+        # event of ANOTHER forked stream (a fork of a fork) sends hip::Stream::EndCapture() of the HIP runtime bundled
+        # with PyTorch 2.10.0+rocm7.0 (torch/lib/libamdhip64.so 7.0.51831) into unbounded recursion -> stack overflow in
+        # capture_end.  Every fork here IS joined; the same topology is fine on ROCm 7.2's own runtime and a missing join
+        # is reported as an error there, not a crash (profiles/r02_capture_crash.txt, tests/tools/capture_probe.hip).
+        # The graph therefore keeps a star topology: modality streams forked from the capture stream, nothing nested.
         self.enabled = (WGRAD_SIDE_STREAM and device.type == "cuda" and str(which) in LANES
-                        and not torch.cuda.is_current_stream_capturing())
+                        and (LANES_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
             self.side = _side_stream(device, which, self.main)
