@@ -96,19 +96,23 @@ class GradAllReducer:
         arenas, self._deferred = self._deferred, None
         return arenas
 
+    def launch_static(self, tensors):
+        """start the in-place all-reduce (average) of tensors at fixed addresses (graph-pool arenas, the staging
+        bucket): ordered after everything enqueued so far on the current stream, running beside what is enqueued next"""
+        return [(self._launch(t), t) for t in tensors]
+
+    def finish_static(self, launched):
+        """the current stream waits for the collectives started by launch_static"""
+        for w, _t in launched:
+            w.wait()
+        if self._avg is None:
+            for _w, t in launched:
+                t.div_(self.world_size)
+
     def reduce_static(self, arenas, flat):
         """all-reduce (average) the recorded arenas and the staging buffer `flat` in place.  The gather of the
         gradients outside the arenas into `flat` and the scatter back are part of the captured graphs."""
-        works = [self._launch(a) for a in arenas]
-        if flat is not None:
-            works.append(self._launch(flat))
-        for w in works:
-            w.wait()
-        if self._avg is None:
-            for a in arenas:
-                a.div_(self.world_size)
-            if flat is not None:
-                flat.div_(self.world_size)
+        self.finish_static(self.launch_static(list(arenas) + ([flat] if flat is not None else [])))
 
     def all_reduce_grads(self):
         """Wait for the per-network collectives started during backward and finish averaging; then reduce, in

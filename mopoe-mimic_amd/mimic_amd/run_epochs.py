@@ -154,9 +154,9 @@ class GraphedTrainStep:
     exactly like the same number of ordinary train steps).  BatchNorm's num_batches_tracked is advanced on the host
     per replay.
 
-    Data parallel (reducer given): no collective is captured.  Graph A = forward + backward, then the gradient
-    arenas are all-reduced eagerly at their fixed addresses (RCCL), then graph B = Adam; the scalar pack is
-    averaged and read back eagerly.
+    Data parallel (reducer given): no collective is captured.  Graph 1 = forward + the decoders' backward, graph 2 = the
+    encoders' backward, graph 3 = Adam; the decoder gradient arenas are all-reduced (RCCL, in place, at their fixed
+    addresses) WHILE graph 2 runs, the encoder arenas after it; the scalar pack is averaged and read back eagerly.
     """
 
     def __init__(self, exp, example_batch, pack: typing.Optional[ScalarPack] = None,
@@ -181,20 +181,43 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.routine = train_step(exp, (dict(self.static), None), None, pack)
         else:
-            # other threads keep making HIP calls here (the process group's watchdog polls events): they must not
-            # invalidate the capture, hence thread_local
+            # Data parallel: the step is THREE graphs on one memory pool, with the collectives (never captured) between
+            # them, so that half of the gradient bytes are reduced while the device still computes:
+            #   graph 1  forward + backward of the three decoders and of the fused latent node, down to the encoders' outputs
+            #            -> RCCL all-reduce of the three decoder arenas starts here and runs beside graph 2
+            #   graph 2  backward of the three encoders; gradients outside the arenas gathered into one staging bucket
+            #            -> all-reduce of the encoder arenas and of the bucket (exposed), wait for everything
+            #   graph 3  scatter of the bucket, Adam
+            # other threads keep making HIP calls meanwhile (the process group's watchdog polls events): they must not
+            # invalidate a capture, hence thread_local
+            model = exp.mm_vae
+            dec_params = [p for n in ("decoder_pa", "decoder_lat", "decoder_text") for p in getattr(model, n).parameters()
+                          if p.requires_grad]
+            self.arenas, self.arenas2, self.outside, self.flat = [], [], [], None
+            self.graph2 = torch.cuda.CUDAGraph()
             self.reducer.begin_deferred()
-            self.arenas, self.outside, self.flat = [], [], None
             try:
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.routine = basic_routine_epoch(exp, (dict(self.static), None))
                     exp.optimizer.zero_grad(set_to_none=True)
-                    self.routine["total_loss"].backward()
+                    enc_outs = [t for pair in self.routine["results"]["latents"]["modalities"].values()
+                                for t in pair if t is not None and t.requires_grad]
+                    grads = torch.autograd.grad(self.routine["total_loss"], enc_outs + dec_params, retain_graph=True,
+                                                allow_unused=True)
+                    enc_grads = list(grads[:len(enc_outs)])
+                    for p_, g_ in zip(dec_params, grads[len(enc_outs):]):
+                        p_.grad = g_            # (arena views, exactly what AccumulateGrad would have adopted)
+                    self.arenas = self.reducer.end_deferred()
+                self.reducer.begin_deferred()
+                with torch.cuda.graph(self.graph2, stream=self.stream, pool=self.graph.pool(),
+                                      capture_error_mode="thread_local"):
+                    keep = [(t, g_) for t, g_ in zip(enc_outs, enc_grads) if g_ is not None]
+                    torch.autograd.backward([t for t, _ in keep], grad_tensors=[g_ for _, g_ in keep])
+                    self.arenas2 = self.reducer.end_deferred()
                     # gradients that do not live in a network arena (stems, heads, latent projections, embedding):
                     # gathered into one staging buffer here, scattered back at the head of the optimiser graph
-                    self.arenas = self.reducer.end_deferred()
-                    ranges = [(a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()) for a in self.arenas]
-                    self.outside = [p.grad for p in exp.mm_vae.parameters()
+                    ranges = [(a.data_ptr(), a.data_ptr() + a.numel() * a.element_size()) for a in self.arenas + self.arenas2]
+                    self.outside = [p.grad for p in model.parameters()
                                     if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)]
                     if self.outside:
                         self.flat = torch.cat([g.reshape(-1) for g in self.outside])
@@ -219,7 +242,10 @@ class GraphedTrainStep:
             self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         if self.reducer is not None:
-            self.reducer.reduce_static(self.arenas, self.flat)
+            early = self.reducer.launch_static(self.arenas)          # decoder arenas: reduced beside graph 2
+            self.graph2.replay()
+            late = self.reducer.launch_static(self.arenas2 + ([self.flat] if self.flat is not None else []))
+            self.reducer.finish_static(early + late)
             self.graph_opt.replay()
             if self.pack is not None:
                 self.pack.submit(self.routine, self.reducer)
