@@ -297,6 +297,9 @@ int mopoe_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_
 int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, void* stream);
 /* embedding with a bf16 activation: out[r, :] = bf16(table[ids[r], :]) (fp32 table); backward scatter-adds the bf16
  * gradient rows into the fp32 dtable (overwritten), skipping padding_idx */
+/* log-softmax backward with the gradient written as bf16 (it enters the vocabulary head's GEMMs as a bf16 operand);
+ * dy and y stay fp32 */
+int mopoe_logsoftmax_bwd_bf16out(const float* dy, const float* y, uint16_t* dx, int64_t rows, int32_t V, void* stream);
 int mopoe_embedding_fwd_bf16(const float* ids, const float* table, uint16_t* out, int64_t rows, int32_t V, int32_t D,
                              void* stream);
 int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtable, int64_t rows, int32_t V, int32_t D,

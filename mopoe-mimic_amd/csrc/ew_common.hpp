@@ -1,5 +1,6 @@
 // Shared pieces of the row-streaming kernels: vector load/store, column layout, per-block column reduction.
 #pragma once
+#include <stdlib.h>
 #include <initializer_list>
 #include "common.hpp"
 
@@ -101,15 +102,23 @@ __device__ void block_col_reduce(const ColLayout& L, bool active, int cbase, int
 }
 
 
+// grid of a row-streaming kernel: at least EW_ROWS_PER_THREAD rows per thread (the per-block column reduction and its
+// atomics amortise over them), at most EW_MAX_BLOCKS blocks.  Both are tuning knobs (env MOPOE_EW_MAX_BLOCKS /
+// MOPOE_EW_ROWS_PER_THREAD, read once): tests/tools/glue_time.py sweeps them.
+static inline int ew_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && atoi(v) > 0 ? atoi(v) : dflt;
+}
 static inline int ew_grid(long rows, int C, int VEC) {
+  static const int max_blocks = ew_env("MOPOE_EW_MAX_BLOCKS", EW_MAX_BLOCKS);
+  static const int rows_per_thread = ew_env("MOPOE_EW_ROWS_PER_THREAD", 8);
   const int Cv = (C + VEC - 1) / VEC;
   const int cols = Cv < EW_THREADS ? Cv : EW_THREADS;
   const int rpp = EW_THREADS / cols;
   long blocks = (rows + rpp - 1) / rpp;
-  // keep several rows per thread so the per-block reduction / atomics amortise
-  blocks = (blocks + 7) / 8;
+  blocks = (blocks + rows_per_thread - 1) / rows_per_thread;
   if (blocks < 1) blocks = 1;
-  if (blocks > EW_MAX_BLOCKS) blocks = EW_MAX_BLOCKS;
+  if (blocks > max_blocks) blocks = max_blocks;
   return (int)blocks;
 }
 

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256) void laplace_nll_bwd_kernel(const float* xh, c
   }
 }
 
+template <typename T> __device__ __forceinline__ T to_store(float f);
+template <> __device__ __forceinline__ float to_store<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t to_store<bf16_t>(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ float from_store(float f) { return f; }
+__device__ __forceinline__ float from_store(bf16_t h) { return bf16_to_f32(h); }
+
 // ---- log-softmax over rows of [rows][V]: one 256-thread block per row, row kept in registers --------
 // NPT = elements per thread (compile-time so the row really stays in VGPRs); V <= 256 * NPT.
 template <int NPT>
@@ -108,13 +114,13 @@ __global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* x, flo
   }
 }
 
-template <int NPT>
-__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* dy, const float* y, float* dx, int V) {
+template <int NPT, typename TO>
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* dy, const float* y, TO* dx, int V) {
   __shared__ float red[4];
   const long row = blockIdx.x;
   const float* dr = dy + row * V;
   const float* yr = y + row * V;
-  float* xr = dx + row * V;
+  TO* xr = dx + row * V;
   float v[NPT];
   float s = 0.f;
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* dy, co
 #pragma unroll
   for (int k = 0; k < NPT; ++k) {
     const int c = threadIdx.x + k * 256;
-    if (c < V) xr[c] = v[k] - expf(yr[c]) * s;
+    if (c < V) xr[c] = to_store<TO>(v[k] - expf(yr[c]) * s);
   }
 }
 
@@ -160,12 +166,6 @@ __global__ __launch_bounds__(256) void token_nll_bwd_kernel(const float* ids, co
 }
 
 // ---- embedding -------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T to_store(float f);
-template <> __device__ __forceinline__ float to_store<float>(float f) { return f; }
-template <> __device__ __forceinline__ bf16_t to_store<bf16_t>(float f) { return f32_to_bf16(f); }
-__device__ __forceinline__ float from_store(float f) { return f; }
-__device__ __forceinline__ float from_store(bf16_t h) { return bf16_to_f32(h); }
-
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* ids, const float* table, T* out, long rows,
                                                           int V, int D) {
@@ -273,10 +273,20 @@ extern "C" int mopoe_logsoftmax_bwd(const float* dy, const float* y, float* dx, 
   if (!dy || !y || !dx || rows <= 0 || V <= 0 || V > 256 * 32) { set_error("logsoftmax_bwd: bad arguments (V <= 8192)"); return MOPOE_ERR_ARG; }
   const dim3 grid((unsigned)rows), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (V <= 256 * 4) hipLaunchKernelGGL(logsoftmax_bwd_kernel<4>, grid, blk, 0, st, dy, y, dx, V);
-  else if (V <= 256 * 16) hipLaunchKernelGGL(logsoftmax_bwd_kernel<16>, grid, blk, 0, st, dy, y, dx, V);
-  else hipLaunchKernelGGL(logsoftmax_bwd_kernel<32>, grid, blk, 0, st, dy, y, dx, V);
+  if (V <= 256 * 4) hipLaunchKernelGGL((logsoftmax_bwd_kernel<4, float>), grid, blk, 0, st, dy, y, dx, V);
+  else if (V <= 256 * 16) hipLaunchKernelGGL((logsoftmax_bwd_kernel<16, float>), grid, blk, 0, st, dy, y, dx, V);
+  else hipLaunchKernelGGL((logsoftmax_bwd_kernel<32, float>), grid, blk, 0, st, dy, y, dx, V);
   return check_launch("logsoftmax_bwd");
+}
+
+extern "C" int mopoe_logsoftmax_bwd_bf16out(const float* dy, const float* y, uint16_t* dx, int64_t rows, int32_t V, void* stream) {
+  if (!dy || !y || !dx || rows <= 0 || V <= 0 || V > 256 * 32) { set_error("logsoftmax_bwd_bf16out: bad arguments (V <= 8192)"); return MOPOE_ERR_ARG; }
+  const dim3 grid((unsigned)rows), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (V <= 256 * 4) hipLaunchKernelGGL((logsoftmax_bwd_kernel<4, bf16_t>), grid, blk, 0, st, dy, y, dx, V);
+  else if (V <= 256 * 16) hipLaunchKernelGGL((logsoftmax_bwd_kernel<16, bf16_t>), grid, blk, 0, st, dy, y, dx, V);
+  else hipLaunchKernelGGL((logsoftmax_bwd_kernel<32, bf16_t>), grid, blk, 0, st, dy, y, dx, V);
+  return check_launch("logsoftmax_bwd_bf16out");
 }
 
 extern "C" int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm, float* out,

@@ -445,16 +445,40 @@ class DecoderText(_HipNet):
             w = wo
         assert w == flags.len_sequence
         self.head_geom = Geom(1, 1, w, 1, w, d, flags.vocab_size, 1, 1, 1, 1, 0, 0, False)
-        # bf16 family: the vocabulary head (V = 3517 is not a multiple of 8) and the log-softmax run in fp32 on the
-        # fp32 master weight; its input / input gradient cross to and from bf16 at the head
+        # The vocabulary head runs on a copy of its weight padded along V to a multiple of 32 (3517 -> 3520: rows of the
+        # logits / of the weight become 16-byte aligned, so the GEMMs take the vector path in fp32 and the bf16 family
+        # applies at all); the pad columns carry bias -1e30, i.e. probability 0, and their weight columns are zero.
+        # The logits and log-probabilities are fp32 in either family.
+        self.vocab, self.vpad = flags.vocab_size, -(-flags.vocab_size // 32) * 32
+        self.head_geom_pad = Geom(1, 1, w, 1, w, d, self.vpad, 1, 1, 1, 1, 0, 0, False)
         self._init_dtype(flags, fp32_mods=[self.head])
+        object.__setattr__(self, "_head_pad", None)
+
+    def _padded_head(self):
+        """(weight [1, d, vpad] in the activation dtype, bias [vpad] fp32) refreshed from the master parameters"""
+        hp = self._head_pad
+        w, b = self.head.weight, self.head.bias
+        if hp is None or hp[0].device != w.device:
+            wp = torch.zeros(1, w.shape[1], self.vpad, dtype=self.act_dtype, device=w.device)
+            bp = torch.full((self.vpad,), -1e30, dtype=torch.float32, device=w.device)
+            hp = [wp, bp, None]
+            object.__setattr__(self, "_head_pad", hp)
+        vers = (w._version, b._version)
+        if self.training or vers != hp[2]:
+            with torch.no_grad():
+                hp[0][:, :, :self.vocab].copy_(w)
+                hp[1][:self.vocab].copy_(b)
+            hp[2] = vers
+        return hp[0], hp[1]
 
     @property
     def head(self):
         return self.text_generator.generator[len(self.text_generator.plan)]
 
     def forward(self, z_style, z_content):
-        (logp,) = self._call(z_content)
+        (logp_pad,) = self._call(z_content)
+        logp = logp_pad[..., :self.vocab]          # what the reference returns: [B, L, V] log-probabilities
+        logp._mopoe_padded = logp_pad              # the contiguous padded tensor, for the fused likelihood reductions
         return [logp]
 
     def _run_forward(self, z):
@@ -467,10 +491,9 @@ class DecoderText(_HipNet):
         h0 = ops.conv_fwd(z4, self._w(self.feature_generator), gl, bias=self.feature_generator.bias, out_stats=st0)
         ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
                                            self.mask_source, arena, b, self._w)
-        gh = self.head_geom.with_batch(b)
-        if self._bf16():
-            ht = ht.float()
-        logits = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
+        gh = self.head_geom_pad.with_batch(b)
+        w_pad, b_pad = self._padded_head()
+        logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
         logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
         if self.training:
             apply_running_updates(running)
@@ -480,13 +503,12 @@ class DecoderText(_HipNet):
         grads: Dict[str, torch.Tensor] = {}
         b = glogp.shape[0]
         gh = sv["gh"]
-        glogits = ops.logsoftmax_bwd(glogp, sv["logp"]).view(b, 1, gh.Ws, gh.Cout)
+        glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
         k = len(self.blocks)
-        grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
-        grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)
-        dht = ops.conv_dgrad(glogits, self.head.weight, gh)
-        if self._bf16():
-            dht = dht.to(self.act_dtype)
+        w_pad = self._head_pad[0]
+        grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()
+        grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)[:self.vocab]
+        dht = ops.conv_dgrad(glogits, w_pad, gh)
         g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)

@@ -726,8 +726,13 @@ def logsoftmax_fwd(x, inplace=False):
     return y
 
 
-def logsoftmax_bwd(dy, y, inplace=False):
+def logsoftmax_bwd(dy, y, inplace=False, out_dtype=None):
+    """out_dtype=bfloat16: the gradient of the logits leaves as a bf16 GEMM operand (dy, y are fp32)"""
     _dev(dy, y)
+    if out_dtype == BF16:
+        dx = torch.empty(dy.shape, dtype=BF16, device=dy.device)
+        _check(lib().mopoe_logsoftmax_bwd_bf16out(_p(dy), _p(y), _p(dx), C.c_int64(_rows(y)), y.shape[-1], _stream()))
+        return dx
     dx = dy if inplace else torch.empty_like(dy)
     _check(lib().mopoe_logsoftmax_bwd(_p(dy), _p(y), _p(dx), C.c_int64(_rows(y)), y.shape[-1], _stream()))
     return dx

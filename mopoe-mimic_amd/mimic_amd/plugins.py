@@ -94,13 +94,17 @@ class FusedOneHotCategorical:
         return (value * self.logits).sum(-1)
 
     def summed_log_prob(self, target_ids, norm_value):
-        """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised)."""
-        return -_TokenNll.apply(self.logits, target_ids, float(norm_value)).view(())
+        """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised).  The text decoder hands over a
+        [..., :V] view of a contiguous tensor padded along V (pad log-probabilities = -1e30): the reductions index the
+        padded tensor directly, so neither a compaction copy nor a slice-gradient pass exists."""
+        lp = getattr(self.logits, "_mopoe_padded", self.logits)
+        return -_TokenNll.apply(lp, target_ids, float(norm_value)).view(())
 
     def log_prob_rows(self, target_ids):
         """per-row sum over the sequence of the picked log-probabilities: logits [R,L,V] against float ids [B,L]
         repeated R/B times (row r <-> r % B); evaluation only."""
-        return ops.token_logprob_rows(self.logits.detach().contiguous(), target_ids.contiguous())
+        lp = getattr(self.logits, "_mopoe_padded", self.logits)
+        return ops.token_logprob_rows(lp.detach().contiguous(), target_ids.contiguous())
 
 
 def get_likelihood(name: str):

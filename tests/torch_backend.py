@@ -334,8 +334,8 @@ def logsoftmax_fwd(x, inplace=False):
     return F.log_softmax(x, dim=-1)
 
 
-def logsoftmax_bwd(dy, y, inplace=False):
-    return dy - torch.exp(y) * dy.sum(-1, keepdim=True)
+def logsoftmax_bwd(dy, y, inplace=False, out_dtype=None):
+    return (dy - torch.exp(y) * dy.sum(-1, keepdim=True)).to(out_dtype or dy.dtype)
 
 
 def token_nll_fwd(logp, ids, norm):
