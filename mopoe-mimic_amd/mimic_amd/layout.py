@@ -86,6 +86,20 @@ class PackedConv(nn.Module):
                                       error_msgs)
 
 
+# Derived copies of parameters (bf16 weight copies, the V-padded vocabulary head) are refreshed on every training
+# forward; in eval mode they are refreshed when a master tensor changed.  A tensor's version counter sees eager in-place
+# updates, but NOT the optimiser step of a replayed hipGraph (no Python runs): the step functions bump this epoch.
+_param_epoch = [0]
+
+
+def note_params_changed():
+    _param_epoch[0] += 1
+
+
+def param_epoch() -> int:
+    return _param_epoch[0]
+
+
 class Bf16Weights:
     """bf16 copies of a network's packed GEMM weights (the MFMA operands of the bf16 family): views into ONE flat
     buffer, refreshed from the fp32 master parameters with one multi-tensor cast.  The same [taps, Cin, Cout] layout
@@ -113,7 +127,7 @@ class Bf16Weights:
         tensor's version counter moved (load_state_dict, manual edits)."""
         if self.flat is None or self.flat.device != self.mods[0].weight.device:
             self._build()
-        vers = [m.weight._version for m in self.mods]
+        vers = (param_epoch(), [m.weight._version for m in self.mods])
         if force or vers != self.versions:
             with torch.no_grad():
                 torch._foreach_copy_([self.views[id(m)] for m in self.mods], [m.weight.detach() for m in self.mods])

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layout import Bf16Weights, BnParams, Indexed, PackedConv, ResBlockParams
+from .layout import Bf16Weights, BnParams, Indexed, PackedConv, ResBlockParams, param_epoch
 from .ops import Geom
 from .trunk import (BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed, trunk_backward,
                     trunk_forward)
@@ -463,7 +463,7 @@ class DecoderText(_HipNet):
             bp = torch.full((self.vpad,), -1e30, dtype=torch.float32, device=w.device)
             hp = [wp, bp, None]
             object.__setattr__(self, "_head_pad", hp)
-        vers = (w._version, b._version)
+        vers = (param_epoch(), w._version, b._version)
         if self.training or vers != hp[2]:
             with torch.no_grad():
                 hp[0][:, :, :self.vocab].copy_(w)

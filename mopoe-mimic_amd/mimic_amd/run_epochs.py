@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .evaluation.losses import calc_joint_elbo_loss, calc_klds, calc_log_probs
+from .layout import note_params_changed
 from .parallel import GradAllReducer
 from .utils.exceptions import CudaOutOfMemory, NaNInLatent
 
@@ -138,6 +139,7 @@ def train_step(exp, batch, reducer=None, pack: typing.Optional[ScalarPack] = Non
     if reducer is not None:
         reducer.all_reduce_grads()
     exp.optimizer.step()
+    note_params_changed()
     if pack is not None:
         pack.submit(routine, reducer)
     return routine
@@ -253,6 +255,7 @@ class GraphedTrainStep:
             self.pack.flush()
         for m, d in self._bn_bump:
             m.pending_batches += d
+        note_params_changed()      # (the replayed optimiser step is invisible to the tensors' version counters)
         return self.routine
 
 
