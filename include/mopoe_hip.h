@@ -230,6 +230,14 @@ int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32
 int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t rows, int32_t V, float norm,
                         float* dlogp, void* stream);
 
+/* OneHotCategorical NLL of a DENSE target (text_encoding='char': modalities/MimicText.py:37-40 passes the
+ * [B, L, num_features] one-hot tensor itself, modalities/Modality.py:25-30 sums target * log p):
+ * out[0] = -sum(target * logp) / norm over n elements.  ws: double[2], zero on entry, left zero.
+ * backward: dlogp = -g[0] / norm * target (overwritten). */
+int mopoe_dense_nll_fwd(const float* logp, const float* target, int64_t n, float norm, float* out, double* ws,
+                        void* stream);
+int mopoe_dense_nll_bwd(const float* target, const float* g, int64_t n, float norm, float* dlogp, void* stream);
+
 /* Per-row log-probabilities for the importance-sampled likelihood estimator (reference:
  * mimic/utils/likelihood.py:119-120,185-186 `likelihood.log_prob(x_rep).view(B*K, -1).sum(dim=1)` on a target repeated
  * K times).  Row r of the decoder output is scored against target row r % target_rows; nothing is repeated in memory.
@@ -238,6 +246,10 @@ int mopoe_token_nll_bwd(const float* ids, const float* g, int64_t rows, int32_t 
 int mopoe_laplace_logprob_rows(const float* x_hat, const float* x, int64_t rows, int64_t per_row,
                                int64_t target_rows, float scale, float* out, void* stream);
 int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, int32_t L, int32_t V,
+                             int64_t target_rows, float* out, void* stream);
+/* text_encoding='char' (MimicText.py:37-40 skips the one-hot step; utils/likelihood.py:103-104): the target IS a dense
+ * [B, L, num_features] tensor: out[r] = sum_i target[(r % target_rows) per_row + i] * logp[r per_row + i] */
+int mopoe_dense_logprob_rows(const float* logp, const float* target, int64_t rows, int64_t per_row,
                              int64_t target_rows, float* out, void* stream);
 
 /* ---- embedding (word_encoding/mmvae_text_enc.py:27-28,73) ------------------------------------------

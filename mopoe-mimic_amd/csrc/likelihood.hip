@@ -78,6 +78,25 @@ template <> __device__ __forceinline__ bf16_t to_store<bf16_t>(float f) { return
 __device__ __forceinline__ float from_store(float f) { return f; }
 __device__ __forceinline__ float from_store(bf16_t h) { return bf16_to_f32(h); }
 
+// ---- dense categorical NLL (char text encoding: the target is a [B, L, F] one-hot / dense tensor) ----------------------
+// out = -sum(target * logp) / norm;  dlogp = -g / norm * target
+__global__ __launch_bounds__(256) void dense_nll_fwd_kernel(const float* logp, const float* tgt, long n, float inv_norm,
+                                                          float* out, double* ws, int nblocks) {
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float t = tgt[i];
+    if (t != 0.f) acc = fmaf(t, logp[i], acc);     // (a one-hot zero must not meet a -inf log-probability)
+  }
+  finish_scalar(block_sum_256(acc), ws, nblocks, -inv_norm, out);
+}
+
+__global__ __launch_bounds__(256) void dense_nll_bwd_kernel(const float* tgt, const float* g, long n, float inv_norm, float* dlogp) {
+  const float c = -g[0] * inv_norm;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dlogp[i] = c * tgt[i];
+}
+
 // ---- log-softmax over rows of [rows][V]: one 256-thread block per row, row kept in registers --------
 // NPT = elements per thread (compile-time so the row really stays in VGPRs); V <= 256 * NPT.
 template <int NPT>
@@ -230,6 +249,17 @@ __global__ __launch_bounds__(256) void token_logprob_rows_kernel(const float* lo
   if (threadIdx.x == 0) out[r] = (float)s;
 }
 
+// out[r] = sum_i target[(r % B) P + i] * logp[r P + i]   (dense / one-hot char targets, P = L * num_features)
+__global__ __launch_bounds__(256) void dense_logprob_rows_kernel(const float* logp, const float* tgt, long P, long B, float* out) {
+  const long r = blockIdx.x;
+  const float* a = logp + r * P;
+  const float* b = tgt + (r % B) * P;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < P; i += 256) acc += a[i] * b[i];
+  const double s = block_sum_256(acc);
+  if (threadIdx.x == 0) out[r] = (float)s;
+}
+
 static int stream_grid(long n, int per_thread) {
   long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (blocks < 1) blocks = 1;
@@ -257,6 +287,21 @@ extern "C" int mopoe_laplace_nll_bwd(const float* x_hat, const float* x, const f
   hipLaunchKernelGGL(laplace_nll_bwd_kernel, dim3(stream_grid(n, 8)), dim3(256), 0, (hipStream_t)stream, x_hat, x, g,
                      (long)n, 1.0f / (scale * norm), dx_hat);
   return check_launch("laplace_nll_bwd");
+}
+
+extern "C" int mopoe_dense_nll_fwd(const float* logp, const float* target, int64_t n, float norm, float* out, double* ws,
+                                   void* stream) {
+  if (!logp || !target || !out || !ws || n <= 0 || norm <= 0.f) { set_error("dense_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
+  const int nb = stream_grid(n, 16);
+  hipLaunchKernelGGL(dense_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logp, target, (long)n, 1.0f / norm, out, ws, nb);
+  return check_launch("dense_nll_fwd");
+}
+
+extern "C" int mopoe_dense_nll_bwd(const float* target, const float* g, int64_t n, float norm, float* dlogp, void* stream) {
+  if (!target || !g || !dlogp || n <= 0 || norm <= 0.f) { set_error("dense_nll_bwd: bad arguments"); return MOPOE_ERR_ARG; }
+  hipLaunchKernelGGL(dense_nll_bwd_kernel, dim3(stream_grid(n, 8)), dim3(256), 0, (hipStream_t)stream, target, g, (long)n,
+                     1.0f / norm, dlogp);
+  return check_launch("dense_nll_bwd");
 }
 
 extern "C" int mopoe_logsoftmax_fwd(const float* x, float* y, int64_t rows, int32_t V, void* stream) {
@@ -316,6 +361,16 @@ extern "C" int mopoe_laplace_logprob_rows(const float* x_hat, const float* x, in
   hipLaunchKernelGGL(laplace_logprob_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x_hat, x, (long)per_row,
                      (long)target_rows, 1.0f / scale, logf(2.0f * scale), out, vec);
   return check_launch("laplace_logprob_rows");
+}
+
+extern "C" int mopoe_dense_logprob_rows(const float* logp, const float* target, int64_t rows, int64_t per_row, int64_t target_rows,
+                                        float* out, void* stream) {
+  if (!logp || !target || !out || rows <= 0 || per_row <= 0 || target_rows <= 0 || rows > 0x7fffffffL) {
+    set_error("dense_logprob_rows: bad arguments"); return MOPOE_ERR_ARG;
+  }
+  hipLaunchKernelGGL(dense_logprob_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logp, target, (long)per_row,
+                     (long)target_rows, out);
+  return check_launch("dense_logprob_rows");
 }
 
 extern "C" int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, int32_t L, int32_t V, int64_t target_rows,

@@ -16,12 +16,17 @@ class Mimic_testing(Dataset):
         self.classifier_training = classifier_training
         self.vocab_size = getattr(flags, "vocab_size", 3517)
         self.flags = flags
-        if getattr(flags, "text_encoding", "word") != "word":
-            raise NotImplementedError("char text encoding is out of scope (needs the absent alphabet.json, SURVEY §2.1)")
 
     def __getitem__(self, index):
         sample = self.get_images() if not getattr(self.flags, "only_text_modality", False) else {}
-        sample["text"] = torch.randint(0, self.vocab_size, (1, self.flags.len_sequence)).view(self.flags.len_sequence).float()
+        if getattr(self.flags, "text_encoding", "word") == "char":
+            # one-hot characters [L, num_features] (what utils/text.py:13-34 makes of a report).  The reference's
+            # Mimic_testing draws dense uniform noise here (:416-417), which OneHotCategorical.log_prob of current torch
+            # rejects as outside its support; the likelihood kernels accept either.
+            ids = torch.randint(0, int(self.flags.num_features), (self.flags.len_sequence,))
+            sample["text"] = torch.nn.functional.one_hot(ids, int(self.flags.num_features)).float()
+        else:
+            sample["text"] = torch.randint(0, self.vocab_size, (1, self.flags.len_sequence)).view(self.flags.len_sequence).float()
         nbr_labels = 1 if getattr(self.flags, "binary_labels", False) else 3
         label = torch.tensor([random.randint(0, 1) for _ in range(nbr_labels)]).float()
         return sample, label

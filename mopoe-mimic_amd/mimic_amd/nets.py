@@ -336,11 +336,17 @@ class _Embedding(nn.Module):
 
 
 class _FeatureExtractorText(nn.Module):
+    """word: mmvae_text_enc.py:22-56 (embedding + stem + 8 blocks); char: char_encoding/FeatureExtractorText.py:28-62 (the
+    stem convolves the [B, L, num_features] input itself, no embedding)"""
+
     def __init__(self, flags):
         super().__init__()
         d = flags.DIM_text
-        self.embedding = _Embedding(flags.vocab_size, d)
-        self.conv1 = PackedConv(d, d, (4,), "conv", True)
+        if flags.text_encoding == "char":
+            self.conv1 = PackedConv(int(flags.num_features), d, (4,), "conv", True)
+        else:
+            self.embedding = _Embedding(flags.vocab_size, d)
+            self.conv1 = PackedConv(d, d, (4,), "conv", True)
         self.plan = [(d, 2 * d, 2, 1), (2 * d, 3 * d, 2, 1), (3 * d, 4 * d, 2, 1), (4 * d, 4 * d, 2, 1),
                      (4 * d, 4 * d, 2, 1), (4 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 0)]
         for i, (ci, co, _s, _p) in enumerate(self.plan):
@@ -350,14 +356,19 @@ class _FeatureExtractorText(nn.Module):
 class EncoderText(_HipNet):
     def __init__(self, flags, style_dim):
         super().__init__()
-        if flags.text_encoding != "word":
-            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
+        if flags.text_encoding not in ("word", "char"):
+            raise ValueError(f"text_encoding must be 'word' or 'char', not {flags.text_encoding!r}")
         self.args = flags
+        self.char = flags.text_encoding == "char"
+        if self.char and compute_dtype(flags) == torch.bfloat16:
+            raise NotImplementedError("the char text networks (71 input features) have no bf16 path: K % 32 != 0")
         self.feature_extractor = _FeatureExtractorText(flags)
         self.feature_compressor = _Compressor(5 * flags.DIM_text, style_dim, flags.class_dim)
         d, length = flags.DIM_text, flags.len_sequence
-        self.stem_geom = Geom(1, 1, length // 2, 1, length, d, d, 1, 4, 1, 2, 0, 1, False)
-        n_run = 8 if length > 500 else 6  # mmvae_text_enc.py:82-84: resblock_7/8 stay unused at L=128
+        cin = int(flags.num_features) if self.char else d
+        self.stem_geom = Geom(1, 1, length // 2, 1, length, cin, d, 1, 4, 1, 2, 0, 1, False)
+        # mmvae_text_enc.py:82-84: resblock_7/8 stay unused at L=128; the char extractor always runs all eight
+        n_run = 8 if (length > 500 or self.char) else 6
         self.blocks: List[BlockSpec] = []
         w = length // 2
         for i in range(n_run):
@@ -377,10 +388,13 @@ class EncoderText(_HipNet):
 
     def _run_forward(self, ids):
         self._begin_forward()
-        b, length = ids.shape
+        b, length = ids.shape[0], ids.shape[1]
         fe = self.feature_extractor
         ids = ids.contiguous()
-        emb = ops.embedding_fwd(ids, fe.embedding.weight, out_dtype=self.act_dtype).view(b, 1, length, -1)
+        if self.char:   # [B, L, num_features] is already the channels-last layout (the reference transposes to NCL)
+            emb = ids.view(b, 1, length, -1)
+        else:
+            emb = ops.embedding_fwd(ids, fe.embedding.weight, out_dtype=self.act_dtype).view(b, 1, length, -1)
         arena = self._arena(self.blocks, ids.device)
         gs = self.stem_geom.with_batch(b)
         st0 = arena.take(gs.Cout)
@@ -399,6 +413,9 @@ class EncoderText(_HipNet):
         g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w)
         grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, sv["gs"])
         grads["feature_extractor.conv1.bias"] = ops.colsum(g0)
+        if self.char:
+            gx = ops.conv_dgrad(g0, self._w(fe.conv1), sv["gs"]).view(sv["ids"].shape) if in_needs_grad[0] else None
+            return [gx], grads, arena
         demb = ops.conv_dgrad(g0, self._w(fe.conv1), sv["gs"])
         grads["feature_extractor.embedding.weight"] = ops.embedding_bwd(sv["ids"], demb, fe.embedding.weight.shape[0], 0)
         return [None], grads, arena
@@ -408,13 +425,25 @@ class EncoderText(_HipNet):
 # text decoder
 # =================================================================================================
 class _DataGeneratorText(nn.Module):
+    """word/len-128: word_encoding/DataGeneratorText.py:29-77 (generator.0-5 + Conv1d k1 head generator.6);
+    char/len-1024: char_encoding/DataGeneratorText.py:25-56 (resblock_1-8 + ConvTranspose1d k4 s2 p1 head conv2)"""
+
     def __init__(self, flags):
         super().__init__()
         d = flags.DIM_text
-        if flags.len_sequence != 128:
-            raise NotImplementedError("the output shapes of this network only work for len_sequence 128 here")
         if getattr(flags, "text_gen_lastlayer", "softmax") != "softmax":
             raise NotImplementedError("only text_gen_lastlayer='softmax' is in scope")
+        if flags.text_encoding == "char":
+            if flags.len_sequence != 1024:
+                raise NotImplementedError("the char generator only closes for len_sequence 1024 (flags.py:157)")
+            self.plan = [(5 * d, 5 * d, 1, 0), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 4 * d, 2, 1),
+                         (4 * d, 4 * d, 2, 1), (4 * d, 3 * d, 2, 1), (3 * d, 2 * d, 2, 1), (2 * d, d, 2, 1)]
+            for i, (ci, co, _s, _p) in enumerate(self.plan):
+                self.add_module(f"resblock_{i + 1}", Indexed(ResBlockParams(ci, co, (4,), True, True, "upsample")))
+            self.conv2 = PackedConv(d, int(flags.num_features), (4,), "convT", True)
+            return
+        if flags.len_sequence != 128:
+            raise NotImplementedError("the output shapes of this network only work for len_sequence 128 here")
         self.plan = [(5 * d, 5 * d, 1, 0), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 4 * d, 2, 1),
                      (4 * d, 4 * d, 2, 1), (4 * d, d, 2, 1)]
         mods = [Indexed(ResBlockParams(ci, co, (4,), True, True, "upsample")) for ci, co, _s, _p in self.plan]
@@ -427,9 +456,12 @@ class DecoderText(_HipNet):
         super().__init__()
         if style_dim:
             raise NotImplementedError("style latents are out of scope (SURVEY §2.1-4)")
-        if flags.text_encoding != "word":
-            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
+        if flags.text_encoding not in ("word", "char"):
+            raise ValueError(f"text_encoding must be 'word' or 'char', not {flags.text_encoding!r}")
         self.flags = flags
+        self.char = flags.text_encoding == "char"
+        if self.char and compute_dtype(flags) == torch.bfloat16:
+            raise NotImplementedError("the char text networks (71 output features) have no bf16 path")
         d = flags.DIM_text
         self.feature_generator = PackedConv(flags.class_dim, 5 * d, (), "linear", True)
         self.text_generator = _DataGeneratorText(flags)
@@ -440,9 +472,21 @@ class DecoderText(_HipNet):
             st_eff = 4 if (st == 1 and w == 1) else st
             g1 = Geom(1, 1, w, 1, w, ci, ci, 1, 1, 1, 1, 0, 0, True)
             g2 = Geom(1, 1, w, 1, wo, ci, co, 1, 4, 1, st_eff, 0, pd, True)
-            blk = self.text_generator.generator[i][0]
-            self.blocks.append(BlockSpec(blk, g1, g2, False, f"text_generator.generator.{i}.0"))
+            if self.char:
+                blk, name = getattr(self.text_generator, f"resblock_{i + 1}")[0], f"text_generator.resblock_{i + 1}.0"
+            else:
+                blk, name = self.text_generator.generator[i][0], f"text_generator.generator.{i}.0"
+            self.blocks.append(BlockSpec(blk, g1, g2, False, name))
             w = wo
+        if self.char:   # head: ConvTranspose1d(d -> num_features, k4 s2 p1), then LogSoftmax over the features
+            nf = int(flags.num_features)
+            self.head_geom = Geom(1, 1, w, 1, 2 * w, d, nf, 1, 4, 1, 2, 0, 1, True)
+            assert 2 * w == flags.len_sequence
+            self.vocab = self.vpad = nf
+            self.head_geom_pad = self.head_geom
+            self._init_dtype(flags)
+            object.__setattr__(self, "_head_pad", None)
+            return
         assert w == flags.len_sequence
         self.head_geom = Geom(1, 1, w, 1, w, d, flags.vocab_size, 1, 1, 1, 1, 0, 0, False)
         # The vocabulary head runs on a copy of its weight padded along V to a multiple of 32 (3517 -> 3520: rows of the
@@ -473,10 +517,14 @@ class DecoderText(_HipNet):
 
     @property
     def head(self):
+        if self.char:
+            return self.text_generator.conv2
         return self.text_generator.generator[len(self.text_generator.plan)]
 
     def forward(self, z_style, z_content):
         (logp_pad,) = self._call(z_content)
+        if self.vpad == self.vocab:
+            return [logp_pad]
         logp = logp_pad[..., :self.vocab]          # what the reference returns: [B, L, V] log-probabilities
         logp._mopoe_padded = logp_pad              # the contiguous padded tensor, for the fused likelihood reductions
         return [logp]
@@ -492,9 +540,13 @@ class DecoderText(_HipNet):
         ht, saved, running = trunk_forward(self.blocks, h0, st0, self.training, self._dropout_on(),
                                            self.mask_source, arena, b, self._w)
         gh = self.head_geom_pad.with_batch(b)
-        w_pad, b_pad = self._padded_head()
-        logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
-        logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
+        if self.char:
+            logits = ops.conv_fwd(ht, self.head.weight, gh, bias=self.head.bias)
+            logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Wb, gh.Cout)
+        else:
+            w_pad, b_pad = self._padded_head()
+            logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
+            logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
         if self.training:
             apply_running_updates(running)
         return (logp,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logp=logp, arena=arena)
@@ -503,12 +555,18 @@ class DecoderText(_HipNet):
         grads: Dict[str, torch.Tensor] = {}
         b = glogp.shape[0]
         gh = sv["gh"]
-        glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
-        k = len(self.blocks)
-        w_pad = self._head_pad[0]
-        grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()
-        grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)[:self.vocab]
-        dht = ops.conv_dgrad(glogits, w_pad, gh)
+        if self.char:
+            glogits = ops.logsoftmax_bwd(glogp, sv["logp"]).view(b, 1, gh.Wb, gh.Cout)
+            grads["text_generator.conv2.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
+            grads["text_generator.conv2.bias"] = ops.colsum(glogits)
+            dht = ops.conv_dgrad(glogits, self.head.weight, gh)
+        else:
+            glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
+            k = len(self.blocks)
+            w_pad = self._head_pad[0]
+            grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()
+            grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)[:self.vocab]
+            dht = ops.conv_dgrad(glogits, w_pad, gh)
         g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
         grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
         grads["feature_generator.bias"] = ops.colsum(g0)

@@ -754,6 +754,23 @@ def token_nll_bwd(ids, g, shape, norm):
     return dlogp
 
 
+def dense_nll_fwd(logp, target, norm):
+    """-sum(target * logp) / norm (char text encoding: dense / one-hot targets)"""
+    _dev(logp, target)
+    assert logp.shape == target.shape
+    out = torch.empty(1, dtype=torch.float32, device=logp.device)
+    _check(lib().mopoe_dense_nll_fwd(_p(logp), _p(target), C.c_int64(logp.numel()), C.c_float(norm), _p(out),
+                                     _p(_ws(logp.device)), _stream()))
+    return out
+
+
+def dense_nll_bwd(target, g, norm):
+    _dev(target, g)
+    dlogp = torch.empty_like(target)
+    _check(lib().mopoe_dense_nll_bwd(_p(target), _p(g), C.c_int64(target.numel()), C.c_float(norm), _p(dlogp), _stream()))
+    return dlogp
+
+
 def laplace_logprob_rows(x_hat, target, scale: float):
     """x_hat [R, ...], target [B, ...] with R a multiple of B -> float [R]: row r scored against target row r % B"""
     _dev(x_hat, target)
@@ -774,6 +791,17 @@ def token_logprob_rows(logp, ids):
     assert ids.shape[1] == L and rows % tb == 0
     out = torch.empty(rows, dtype=torch.float32, device=logp.device)
     _check(lib().mopoe_token_logprob_rows(_p(logp), _p(ids), C.c_int64(rows), L, V, C.c_int64(tb), _p(out), _stream()))
+    return out
+
+
+def dense_logprob_rows(logp, target):
+    """logp [R, L, F] log-probabilities, target [B, L, F] dense / one-hot, R a multiple of B -> float [R]"""
+    _dev(logp, target)
+    rows, tb = logp.shape[0], target.shape[0]
+    per_row = logp[0].numel()
+    assert target[0].numel() == per_row and rows % tb == 0
+    out = torch.empty(rows, dtype=torch.float32, device=logp.device)
+    _check(lib().mopoe_dense_logprob_rows(_p(logp), _p(target), C.c_int64(rows), C.c_int64(per_row), C.c_int64(tb), _p(out), _stream()))
     return out
 
 

@@ -47,6 +47,22 @@ class _TokenNll(torch.autograd.Function):
         return ops.token_nll_bwd(ids, g.contiguous(), ctx.shape, ctx.norm), None, None
 
 
+class _DenseNll(torch.autograd.Function):
+    """-sum(target * logp) / norm for a dense / one-hot target of logp's shape (char text encoding)"""
+
+    @staticmethod
+    def forward(ctx, logp, target, norm):
+        tgt = target.contiguous()
+        ctx.save_for_backward(tgt)
+        ctx.norm = norm
+        return ops.dense_nll_fwd(logp.contiguous(), tgt, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (tgt,) = ctx.saved_tensors
+        return ops.dense_nll_bwd(tgt, g.contiguous(), ctx.norm), None, None
+
+
 class FusedLaplace:
     """Stand-in for torch.distributions.Laplace(loc, scale) as the image decoders' output."""
 
@@ -97,12 +113,16 @@ class FusedOneHotCategorical:
         """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised).  The text decoder hands over a
         [..., :V] view of a contiguous tensor padded along V (pad log-probabilities = -1e30): the reductions index the
         padded tensor directly, so neither a compaction copy nor a slice-gradient pass exists."""
+        if target_ids.dim() == self.logits.dim():   # char encoding: the [B, L, num_features] one-hot tensor itself
+            return -_DenseNll.apply(self.logits, target_ids, float(norm_value)).view(())
         lp = getattr(self.logits, "_mopoe_padded", self.logits)
         return -_TokenNll.apply(lp, target_ids, float(norm_value)).view(())
 
     def log_prob_rows(self, target_ids):
         """per-row sum over the sequence of the picked log-probabilities: logits [R,L,V] against float ids [B,L]
         repeated R/B times (row r <-> r % B); evaluation only."""
+        if target_ids.dim() == self.logits.dim():   # char encoding: dense [B, L, num_features] target
+            return ops.dense_logprob_rows(self.logits.detach().contiguous(), target_ids.contiguous())
         lp = getattr(self.logits, "_mopoe_padded", self.logits)
         return ops.token_logprob_rows(lp.detach().contiguous(), target_ids.contiguous())
 
@@ -170,13 +190,18 @@ class MimicLateral(_MimicImage):
 
 class MimicText(Modality):
     def __init__(self, enc, dec, len_sequence, plotImgSize, font, args):
-        if args.text_encoding != "word":
-            raise NotImplementedError("only text_encoding='word' is in scope (SURVEY §2.1-7)")
         self.name = "text"
         self.args = args
         self.likelihood_name = "categorical"
         self.len_sequence = len_sequence
-        self.data_size = torch.Size((args.vocab_size, len_sequence))
+        if args.text_encoding == "char":     # MimicText.py:19-21 (only the LENGTH of the alphabet enters the arithmetic)
+            self.alphabet = getattr(args, "alphabet", None)
+            nf = len(self.alphabet) if self.alphabet else int(args.num_features)
+            self.data_size = torch.Size((nf, len_sequence))
+        elif args.text_encoding == "word":
+            self.data_size = torch.Size((args.vocab_size, len_sequence))
+        else:
+            raise ValueError(f"text_encoding must be 'word' or 'char', not {args.text_encoding!r}")
         self.plot_img_size, self.font = plotImgSize, font
         self.gen_quality_eval = False
         self.file_suffix = ".txt"
@@ -190,6 +215,11 @@ class MimicText(Modality):
         raise NotImplementedError("plotting is outside the training hot path (SURVEY §2.1-17)")
 
     def calc_log_prob(self, out_dist, target: torch.Tensor, norm_value: int):
+        # reference MimicText.py:37-40: word targets are one-hot encoded first, char targets ARE [B, L, num_features]
+        if self.args.text_encoding == "char":
+            if hasattr(out_dist, "summed_log_prob"):
+                return out_dist.summed_log_prob(target, norm_value)
+            return out_dist.log_prob(target).sum() / norm_value
         if hasattr(out_dist, "summed_log_prob") and target.dim() == out_dist.logits.dim() - 1:
             return out_dist.summed_log_prob(target, norm_value)  # float ids, as the data loader yields them
         onehot = torch.nn.functional.one_hot(target.to(torch.int64), num_classes=self.args.vocab_size)

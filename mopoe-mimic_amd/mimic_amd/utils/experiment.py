@@ -20,6 +20,7 @@ def default_flags(**overrides) -> argparse.Namespace:
     f = argparse.Namespace(
         img_size=128, image_channels=1, DIM_img=64, DIM_text=128, class_dim=128, batch_size=64,
         style_pa_dim=0, style_lat_dim=0, style_text_dim=0, text_encoding="word", len_sequence=128,
+        num_features=71,   # text_encoding='char': alphabet size (experiment.py:49-51); len_sequence is then 1024 (flags.py:157)
         vocab_size=3517, text_gen_lastlayer="softmax", feature_extractor_img="resnet",
         factorized_representation=False, method="joint_elbo", modality_poe=False, modality_moe=False,
         modality_jsd=False, joint_elbo=True, poe_unimodal_elbos=False, only_text_modality=False,

@@ -13,6 +13,7 @@ Fixtures:
                          checksums, per-network gradient norms
   g2_edges.npz           mixture partition for B in {7,8,32,56,63,64,65,256}, partial-modality inference
   g3_traj.npz            3 Adam steps of losses (train_nodrop)
+  g5_char.npz            text_encoding='char' (char_encoding networks, dense categorical likelihood): as g0
 Usage:  python oracle/gen_golden.py [--only g0_s64 ...]
 """
 from __future__ import annotations
@@ -73,7 +74,12 @@ def make_flags(cfg: R.Cfg):
     f.method = "joint_elbo"
     f = get_method(f)
     f = flags_set_alpha_modalities(f)
-    f.text_encoding, f.len_sequence, f.vocab_size = "word", cfg.len_sequence, cfg.vocab_size
+    f.text_encoding, f.len_sequence, f.vocab_size = cfg.text_encoding, cfg.len_sequence, cfg.vocab_size
+    if cfg.text_encoding == "char":
+        # the char networks only read num_features; MimicText reads len(alphabet).  alphabet.json is absent from the
+        # reference checkout (.gitignore:138), and its CONTENT plays no role in the arithmetic: any 71 symbols do
+        f.num_features = cfg.num_features
+        f.alphabet = "".join(chr(48 + i) for i in range(cfg.num_features))
     f.device = torch.device("cpu")
     f.dataset = "testing"
     f.beta, f.beta_content = cfg.beta, cfg.beta_content
@@ -202,7 +208,11 @@ def pack_outputs(prefix, out, cap, model, store, rec_stride=1):
 def batch_to_store(batch, store, prefix="in"):
     store[f"{prefix}/PA_u8"] = (batch["PA"] * 255.0).round().to(torch.uint8).numpy()
     store[f"{prefix}/Lateral_u8"] = (batch["Lateral"] * 255.0).round().to(torch.uint8).numpy()
-    store[f"{prefix}/text"] = batch["text"].to(torch.int32).numpy()
+    if batch["text"].dim() == 3:   # char encoding: one-hot [B, L, num_features], stored as character ids
+        assert bool(((batch["text"] == 0) | (batch["text"] == 1)).all()) and bool((batch["text"].sum(-1) == 1).all())
+        store[f"{prefix}/text_ids"] = batch["text"].argmax(-1).to(torch.int32).numpy()
+    else:
+        store[f"{prefix}/text"] = batch["text"].to(torch.int32).numpy()
 
 
 def break_ties(run_epochs, cfg, sd, batch, modes, margin=2e-3, max_iter=40):
@@ -277,6 +287,45 @@ def gen_g0(run_epochs, size, nrow):
         exp = build_reference(cfg, sd)
         out, cap = run_reference(run_epochs, exp, batch, mode)
         pack_outputs(mode, out, cap, exp.mm_vae, store, rec_stride=size // 64)
+        for name, p in exp.mm_vae.named_parameters():
+            if p.grad is not None:
+                store[f"{mode}/grad/{name}"] = p.grad.numpy()
+        if mode != "eval":
+            for name, b in exp.mm_vae.named_buffers():
+                if name.endswith("running_mean") or name.endswith("running_var"):
+                    store[f"{mode}/buf/{name}"] = b.detach().numpy()
+    return store
+
+
+def gen_g5_char(run_epochs):
+    """text_encoding='char' (mimic/networks/char_encoding/*.py: [B, 1024, 71] input, 8 residual blocks each way,
+    ConvTranspose1d head, dense sum(target * log p) likelihood): the whole tri-modal step in eval / train_nodrop / train,
+    every parameter gradient -- the same content as G0, for the char text networks."""
+    nrow = 3
+    cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=nrow, text_encoding="char",
+                len_sequence=1024, num_features=71)
+    for attempt in range(30):
+        sd = R.init_state(cfg, seed=500 + 1000 * attempt)
+        batch, _ = R.synthetic_batch(cfg, nrow, seed=77 + 1000 * attempt)
+        batch = break_ties(run_epochs, cfg, sd, batch, ("eval", "train_nodrop", "train"))
+        cond = conditioning(run_epochs, cfg, sd, batch, ("eval", "train_nodrop"))
+        print(f"g5_char attempt {attempt}: fp32-vs-fp64 deviation of the reference = {cond:.2e}")
+        if cond < 3e-4:
+            break
+    else:
+        raise RuntimeError("no well-conditioned fixture found")
+    store = {"cfg": np.array([64, cfg.class_dim, cfg.DIM_img, cfg.DIM_text, cfg.vocab_size, nrow]),
+             "num_features": np.array(cfg.num_features), "len_sequence": np.array(cfg.len_sequence),
+             "rec_stride": np.array(1)}
+    for k, v in sd.items():
+        store[f"sd/{k}"] = v.numpy()
+    batch_to_store(batch, store)
+    for mode in ("eval", "train_nodrop", "train"):
+        exp = build_reference(cfg, sd)
+        out, cap = run_reference(run_epochs, exp, batch, mode)
+        pack_outputs(mode, out, cap, exp.mm_vae, store, rec_stride=1)
+        store[f"{mode}/rec/text"] = store[f"{mode}/rec/text"][:, ::16]     # every 16th position (+ checksums) keeps it small
+        store[f"{mode}/recchk/text"] = checksums(out["results"]["rec"]["text"].logits)
         for name, p in exp.mm_vae.named_parameters():
             if p.grad is not None:
                 store[f"{mode}/grad/{name}"] = p.grad.numpy()
@@ -441,6 +490,7 @@ def main():
         "g2_edges": lambda: gen_g2(run_epochs),
         "g3_traj": lambda: gen_g3(run_epochs),
         "g4_likelihood": lambda: gen_g4(run_epochs),
+        "g5_char": lambda: gen_g5_char(run_epochs),
     }
     for name, job in jobs.items():
         if args.only and name not in args.only:

@@ -19,6 +19,8 @@ Reference citations (relative to /root/reference):
   residual blocks      mimic/networks/ResidualBlocks.py:5-131
   text encoder         mimic/networks/ConvNetworksTextMimic.py:11-36, word_encoding/mmvae_text_enc.py:22-85
   text decoder         mimic/networks/ConvNetworksTextMimic.py:39-68, word_encoding/DataGeneratorText.py:29-98
+  char text networks   mimic/networks/char_encoding/FeatureExtractorText.py:28-81, char_encoding/DataGeneratorText.py:25-76
+                       (text_encoding='char': [B, 1024, 71] inputs, 8 residual blocks each way, ConvTranspose1d head)
   latent compressor    mimic/networks/FeatureCompressor.py:4-28
   subset PoE + MoE     mimic/utils/BaseMMVae.py:139-196, evaluation/divergence_measures/mm_div.py:10-17
   mixture selection    mimic/utils/utils.py:51-77
@@ -53,6 +55,8 @@ class Cfg:
     vocab_size: int = 3517
     len_sequence: int = 128
     image_channels: int = 1
+    text_encoding: str = "word"  # 'word' (ids [B, L]) or 'char' (dense / one-hot [B, 1024, num_features], flags.py:48,157)
+    num_features: int = 71       # alphabet size of the char encoding (experiment.py:49-51)
     batch_size: int = 64  # flags.batch_size: the NORMALISER (kl_div.py:14-15, Modality.py:30)
     beta: float = 1.0
     beta_content: float = 1.0
@@ -96,10 +100,16 @@ def text_enc_blocks(cfg: Cfg) -> List[Tuple[int, int, int, int]]:
 
 
 def text_dec_blocks(cfg: Cfg) -> List[Tuple[int, int, int, int]]:
-    """word/len-128 plan (word_encoding/DataGeneratorText.py:33-68)."""
+    """word/len-128 plan (word_encoding/DataGeneratorText.py:33-68); char/len-1024 plan
+    (char_encoding/DataGeneratorText.py:28-50: resblock_1..8, then the ConvTranspose1d head conv2)."""
+    d = cfg.DIM_text
+    if cfg.text_encoding == "char":
+        if cfg.len_sequence != 1024:
+            raise NotImplementedError("the char networks only close for len_sequence = 1024 (flags.py:157)")
+        return [(5 * d, 5 * d, 1, 0), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 4 * d, 2, 1),
+                (4 * d, 4 * d, 2, 1), (4 * d, 3 * d, 2, 1), (3 * d, 2 * d, 2, 1), (2 * d, d, 2, 1)]
     if cfg.len_sequence != 128:
         raise NotImplementedError("only the word / len_sequence=128 path is in scope (SURVEY §2.1-7)")
-    d = cfg.DIM_text
     return [(5 * d, 5 * d, 1, 0), (5 * d, 5 * d, 2, 1), (5 * d, 5 * d, 2, 1), (5 * d, 4 * d, 2, 1),
             (4 * d, 4 * d, 2, 1), (4 * d, d, 2, 1)]
 
@@ -168,19 +178,28 @@ def init_state(cfg: Cfg, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.
              bias=True, transposed=True)
 
     d = cfg.DIM_text
-    sd["encoder_text.feature_extractor.embedding.weight"] = torch.randn(
-        (cfg.vocab_size, d), generator=g, dtype=torch.float64).to(dtype)
-    sd["encoder_text.feature_extractor.embedding.weight"][0].zero_()  # padding_idx=0 (mmvae_text_enc.py:27)
-    conv("encoder_text.feature_extractor.conv1", d, d, 4, bias=True)
+    char = cfg.text_encoding == "char"
+    if char:   # no embedding: the stem convolves the [B, L, num_features] input itself
+        conv("encoder_text.feature_extractor.conv1", d, cfg.num_features, 4, bias=True)
+    else:
+        sd["encoder_text.feature_extractor.embedding.weight"] = torch.randn(
+            (cfg.vocab_size, d), generator=g, dtype=torch.float64).to(dtype)
+        sd["encoder_text.feature_extractor.embedding.weight"][0].zero_()  # padding_idx=0 (mmvae_text_enc.py:27)
+        conv("encoder_text.feature_extractor.conv1", d, d, 4, bias=True)
     for i, (ci, co, _s, _p) in enumerate(text_enc_blocks(cfg)):
         resblock(f"encoder_text.feature_extractor.resblock_{i + 1}.0", ci, co, (4,), False, True, "downsample")
     linear("encoder_text.feature_compressor.content_mu", cfg.class_dim, 5 * d)
     linear("encoder_text.feature_compressor.content_logvar", cfg.class_dim, 5 * d)
     linear("decoder_text.feature_generator", 5 * d, cfg.class_dim)
     tblocks = text_dec_blocks(cfg)
-    for i, (ci, co, _s, _p) in enumerate(tblocks):
-        resblock(f"decoder_text.text_generator.generator.{i}.0", ci, co, (4,), True, True, "upsample")
-    conv(f"decoder_text.text_generator.generator.{len(tblocks)}", cfg.vocab_size, d, 1, bias=True)
+    if char:   # char_encoding/DataGeneratorText.py: resblock_1..8 + conv2 (ConvTranspose1d d -> num_features, k4 s2 p1)
+        for i, (ci, co, _s, _p) in enumerate(tblocks):
+            resblock(f"decoder_text.text_generator.resblock_{i + 1}.0", ci, co, (4,), True, True, "upsample")
+        conv("decoder_text.text_generator.conv2", cfg.num_features, d, 4, bias=True, transposed=True)
+    else:
+        for i, (ci, co, _s, _p) in enumerate(tblocks):
+            resblock(f"decoder_text.text_generator.generator.{i}.0", ci, co, (4,), True, True, "upsample")
+        conv(f"decoder_text.text_generator.generator.{len(tblocks)}", cfg.vocab_size, d, 1, bias=True)
     return sd
 
 
@@ -337,11 +356,14 @@ def decode_img(cfg: Cfg, sd, name: str, z, ctx: Ctx):
 def encode_text(cfg: Cfg, sd, x_ids, ctx: Ctx):
     """EncoderText.forward (ConvNetworksTextMimic.py:23-36): float ids [B,L] -> (mu, logvar)."""
     p = "encoder_text.feature_extractor"
-    h = _q(F.embedding(x_ids.long(), sd[p + ".embedding.weight"], padding_idx=0), ctx)
+    if cfg.text_encoding == "char":   # char_encoding/FeatureExtractorText.py:70-80: x [B, L, num_features]
+        h = x_ids
+    else:
+        h = _q(F.embedding(x_ids.long(), sd[p + ".embedding.weight"], padding_idx=0), ctx)
     h = h.transpose(-2, -1)
     h = _q(F.conv1d(h, _qw(sd[p + ".conv1.weight"], ctx), sd[p + ".conv1.bias"], stride=2, padding=1), ctx)
     blocks = text_enc_blocks(cfg)
-    n_run = 8 if cfg.len_sequence > 500 else 6  # mmvae_text_enc.py:82-84
+    n_run = 8 if (cfg.len_sequence > 500 or cfg.text_encoding == "char") else 6  # mmvae_text_enc.py:82-84
     for i in range(n_run):
         _ci, _co, s, pd = blocks[i]
         h = _resblock(sd, f"{p}.resblock_{i + 1}.0", h, ctx, stride=s, pad=pd, transposed=False,
@@ -354,8 +376,15 @@ def decode_text(cfg: Cfg, sd, z, ctx: Ctx):
     h = _q(F.linear(_q(z, ctx), _qw(sd["decoder_text.feature_generator.weight"], ctx),
                     sd["decoder_text.feature_generator.bias"]), ctx)
     h = h.unsqueeze(-1)
-    p = "decoder_text.text_generator.generator"
     blocks = text_dec_blocks(cfg)
+    if cfg.text_encoding == "char":   # char_encoding/DataGeneratorText.py:51-76
+        p = "decoder_text.text_generator"
+        for i, (_ci, _co, s, pd) in enumerate(blocks):
+            h = _resblock(sd, f"{p}.resblock_{i + 1}.0", h, ctx, stride=s, pad=pd, transposed=True, twod=False,
+                          short_name="upsample")
+        logits = F.conv_transpose1d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], stride=2, padding=1)
+        return F.log_softmax(logits, dim=1).transpose(-2, -1)
+    p = "decoder_text.text_generator.generator"
     for i, (_ci, _co, s, pd) in enumerate(blocks):
         h = _resblock(sd, f"{p}.{i}.0", h, ctx, stride=s, pad=pd, transposed=True, twod=False,
                       short_name="upsample")
@@ -440,6 +469,8 @@ def categorical_nll(logp, target_ids, norm):
     """-sum onehot(target)*normalised(logits) / norm (MimicText.py:37-40; OneHotCategorical
     re-normalises its logits: logits - logsumexp(logits))."""
     logp = logp - torch.logsumexp(logp, dim=-1, keepdim=True)
+    if target_ids.dim() == logp.dim():   # char encoding: the target is a [B, L, num_features] one-hot tensor:
+        return -(target_ids * logp).sum() / norm   # OneHotCategorical.log_prob = sum(target * log p)
     picked = torch.gather(logp, -1, target_ids.long().unsqueeze(-1))
     return -picked.sum() / norm
 
@@ -520,10 +551,14 @@ def likelihood_estimates(cfg: Cfg, sd, batch, subset_posterior, eps, scale: floa
         tgt = batch[m].unsqueeze(0).repeat(k, 1, 1, 1, 1).view(k * b, *batch[m].shape[1:])
         lp = -math.log(2 * scale) - torch.abs(tgt - rec[m]) / scale           # Laplace(loc, 0.75).log_prob
         log_px[m] = lp.view(k * b, -1).sum(dim=1)
-    ids = batch["text"].long().unsqueeze(0).repeat(k, 1, 1).view(k * b, -1)
     # OneHotCategorical(logits).log_prob(one_hot) = sum over the vocabulary of one_hot * normalised logits
     norm_logits = logp_text - torch.logsumexp(logp_text, dim=-1, keepdim=True)
-    log_px["text"] = norm_logits.gather(-1, ids.unsqueeze(-1)).squeeze(-1).sum(dim=1)
+    if cfg.text_encoding == "char":   # the [B, L, num_features] target enters as it is (likelihood.py:103-104)
+        tgt = batch["text"].unsqueeze(0).repeat(k, 1, 1, 1).view(k * b, *batch["text"].shape[1:])
+        log_px["text"] = (tgt * norm_logits).sum(-1).sum(dim=1)
+    else:
+        ids = batch["text"].long().unsqueeze(0).repeat(k, 1, 1).view(k * b, -1)
+        log_px["text"] = norm_logits.gather(-1, ids.unsqueeze(-1)).squeeze(-1).sum(dim=1)
     log_q = gaussian_log_pdf(z, mu_r, lv_r)
     log_pz = unit_gaussian_log_pdf(z)
     out = {}
@@ -557,7 +592,14 @@ def synthetic_batch(cfg: Cfg, nrow: int, seed: int):
     s = cfg.img_size
     pa = torch.randint(0, 256, (nrow, 1, s, s), generator=g).float() / 255.0
     lat = torch.randint(0, 256, (nrow, 1, s, s), generator=g).float() / 255.0
-    text = torch.randint(0, cfg.vocab_size, (nrow, cfg.len_sequence), generator=g).float()
+    if cfg.text_encoding == "char":
+        # one-hot characters [L, num_features], as utils/text.py:13-34 (one_hot_encode) produces on real reports.  (The
+        # reference's Mimic_testing draws dense uniform noise here, MimicDataset.py:416-417, which current torch's
+        # OneHotCategorical.log_prob rejects as outside its support.)
+        ids = torch.randint(0, cfg.num_features, (nrow, cfg.len_sequence), generator=g)
+        text = F.one_hot(ids, cfg.num_features).float()
+    else:
+        text = torch.randint(0, cfg.vocab_size, (nrow, cfg.len_sequence), generator=g).float()
     eps = torch.randn((nrow, cfg.class_dim), generator=g)
     return {"PA": pa, "Lateral": lat, "text": text}, eps
 

@@ -13,6 +13,11 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+def char_cfg(g):
+    """Cfg of a text_encoding='char' fixture (g5_char)"""
+    return cfg_from(g["cfg"], text_encoding="char", len_sequence=int(g["len_sequence"]), num_features=int(g["num_features"]))
+
+
 def cfg_from(arr, **kw):
     size, cdim, dimg, dtext, vocab, nrow = [int(v) for v in arr]
     return R.Cfg(img_size=size, class_dim=cdim, DIM_img=dimg, DIM_text=dtext, vocab_size=vocab,
@@ -24,9 +29,13 @@ def g0_state(g):
 
 
 def g0_batch(g):
+    if "in/text_ids" in g.files:   # char encoding: one-hot [B, L, num_features] rebuilt from the stored character ids
+        text = torch.nn.functional.one_hot(torch.from_numpy(g["in/text_ids"]).long(), int(g["num_features"])).float()
+    else:
+        text = torch.from_numpy(g["in/text"]).float()
     return {"PA": torch.from_numpy(g["in/PA_u8"]).float() / 255.0,
             "Lateral": torch.from_numpy(g["in/Lateral_u8"]).float() / 255.0,
-            "text": torch.from_numpy(g["in/text"]).float()}
+            "text": text}
 
 
 def g0_masks(g, mode="train"):

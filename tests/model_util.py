@@ -10,7 +10,8 @@ def build_exp(cfg: R.Cfg, sd, device, mode="train_nodrop", masks=None, eps=None,
     flags = default_flags(img_size=cfg.img_size, class_dim=cfg.class_dim, DIM_img=cfg.DIM_img,
                           DIM_text=cfg.DIM_text, vocab_size=cfg.vocab_size, batch_size=cfg.batch_size,
                           beta=cfg.beta, beta_content=cfg.beta_content, device=torch.device(device),
-                          compute_dtype=compute_dtype)
+                          compute_dtype=compute_dtype, text_encoding=getattr(cfg, "text_encoding", "word"),
+                          len_sequence=cfg.len_sequence, num_features=getattr(cfg, "num_features", 71))
     exp = HotPathExperiment(flags)
     model = exp.mm_vae
     missing = model.load_state_dict(sd, strict=True)

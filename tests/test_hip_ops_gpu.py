@@ -348,6 +348,26 @@ def test_laplace_logprob_rows(rows, tb, per_row):
     check("laplace_logprob_rows/unaligned", got, ref, rtol=2e-6, atol_rel=2e-6)
 
 
+@pytest.mark.parametrize("b,L,F,onehot", [(4, 1024, 71, True), (3, 37, 5, False), (1, 1, 1, False), (16, 1024, 71, False)])
+def test_dense_nll_and_rows(b, L, F, onehot):
+    """text_encoding='char' likelihood (MimicText.py:37-40): dense [B, L, F] targets, one-hot or not"""
+    gen = torch.Generator().manual_seed(b * L + F)
+    logp = torch.log_softmax(torch.randn(b, L, F, generator=gen), dim=-1)
+    if onehot:
+        tgt = torch.nn.functional.one_hot(torch.randint(0, F, (b, L), generator=gen), F).float()
+    else:
+        tgt = torch.rand(b, L, F, generator=gen)
+    ref = TB.dense_nll_fwd(logp.double(), tgt.double(), float(b))
+    got = ops.dense_nll_fwd(logp.to(DEV), tgt.to(DEV), float(b))
+    check("dense_nll_fwd", got.view(-1), ref.view(-1), rtol=2e-6, atol_rel=2e-6)
+    g = torch.tensor(0.37)
+    check("dense_nll_bwd", ops.dense_nll_bwd(tgt.to(DEV), g.to(DEV), float(b)), TB.dense_nll_bwd(tgt, g, float(b)), rtol=1e-6, atol_rel=1e-7)
+    k = 3
+    lp_rep = torch.log_softmax(torch.randn(k * b, L, F, generator=gen), dim=-1)
+    check("dense_logprob_rows", ops.dense_logprob_rows(lp_rep.to(DEV), tgt.to(DEV)), TB.dense_logprob_rows(lp_rep.double(), tgt.double()),
+          rtol=2e-6, atol_rel=2e-6)
+
+
 @pytest.mark.parametrize("rows,tb,L,V", [(12, 4, 128, 50), (6, 3, 300, 3517), (5, 5, 1, 9)])
 def test_token_logprob_rows(rows, tb, L, V):
     gen = torch.Generator().manual_seed(rows + V)

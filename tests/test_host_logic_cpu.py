@@ -262,3 +262,48 @@ def test_bf16_host_logic_matches_oracle_bf16_mode(monkeypatch):
         if b.norm().item() > 2e-2 * scale * b.numel() ** 0.5:
             cos.append((torch.dot(a, b) / (a.norm() * b.norm())).item())
     assert len(cos) > 150 and np.median(cos) > 0.995 and min(cos) > 0.9, (len(cos), np.median(cos), min(cos))
+
+
+@pytest.mark.parametrize("mode", ["eval", "train_nodrop", "train"])
+def test_g5_char_encoding_host_logic(monkeypatch, mode):
+    """text_encoding='char' (reference mimic/networks/char_encoding/*.py): the product's char text networks -- state_dict keys
+    of the reference, 8 residual blocks each way, ConvTranspose1d head, dense categorical likelihood -- against the
+    reference-generated fixture G5 (torch emulation of the ops; the HIP run is tests/test_model_gpu.py)."""
+    from golden_util import char_cfg
+    torch_backend.install(monkeypatch)
+    g = load("g5_char")
+    cfg = char_cfg(g)
+    exp = build_exp(cfg, g0_state(g), "cpu", mode, masks=g0_masks(g) if mode == "train" else None,
+                    eps=torch.from_numpy(g[f"{mode}/eps"]))
+    check_char_against_g5(exp, g, mode, g0_batch(g), "cpu")
+
+
+def check_char_against_g5(exp, g, mode, batch, device, rtol=1e-4, atol=1e-5, grad_rtol=1e-3, grad_atol=1e-3):
+    assert set(exp.mm_vae.state_dict().keys()) == {k[3:] for k in g.files if k.startswith("sd/")}
+    out = RE.basic_routine_epoch(exp, ({k: v.clone().to(device) for k, v in batch.items()}, None))
+    res, lat = out["results"], out["results"]["latents"]
+    for m in R.MOD_ORDER:
+        close(lat["modalities"][m][0], g[f"{mode}/enc/{m}/mu"], rtol, atol, m)
+        close(lat["modalities"][m][1], g[f"{mode}/enc/{m}/logvar"], rtol, atol, m)
+    close(lat["mus"], g[f"{mode}/mus"], rtol, atol)
+    close(lat["joint"][0], g[f"{mode}/joint/mu"], rtol, atol)
+    close(res["individual_divs"], g[f"{mode}/individual_divs"], rtol, atol)
+    logp = res["rec"]["text"].logits
+    assert tuple(logp.shape) == (batch["text"].shape[0], 1024, 71)
+    close(logp[:, ::16], g[f"{mode}/rec/text"], 10 * rtol, 10 * atol)
+    np.testing.assert_allclose(checksums(logp), g[f"{mode}/recchk/text"], rtol=10 * rtol, atol=1e-2)
+    for k, v in out["log_probs"].items():
+        close(v, g[f"{mode}/log_probs/{k}"], rtol, atol, k)
+    close(out["total_loss"], g[f"{mode}/total_loss"], rtol, atol)
+    exp.mm_vae.zero_grad()
+    out["total_loss"].backward()
+    grads = exp.mm_vae.reference_named_grads()
+    pre = f"{mode}/grad/"
+    names = [k[len(pre):] for k in g.files if k.startswith(pre)]
+    assert set(names) == set(grads.keys()), set(names) ^ set(grads.keys())
+    for name in names:
+        ref = g[pre + name]
+        scale = max(np.abs(ref).max(), 1e-3)
+        if name.endswith(".bias") and (pre + name[:-4] + "weight") in g.files:
+            scale = max(scale, np.abs(g[pre + name[:-4] + "weight"]).max())
+        np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=grad_rtol, atol=grad_atol * scale, err_msg=name)

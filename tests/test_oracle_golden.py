@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import mopoe_ref as R
-from golden_util import load, cfg_from, g0_state, g0_batch, g0_masks, checksums
+from golden_util import load, cfg_from, char_cfg, g0_state, g0_batch, g0_masks, checksums
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):
@@ -72,6 +72,39 @@ def test_g0_full(size, mode):
             if "resblock_7" in name or "resblock_8" in name:
                 continue
             close(ctx.new_running[name], g[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train_nodrop", "train"])
+def test_g5_char_encoding(mode):
+    """text_encoding='char' (mimic/networks/char_encoding/*.py) against the reference's own run: latents, reconstructions,
+    likelihoods, loss and the gradient of EVERY parameter (all 8 text residual blocks are live here)."""
+    g = load("g5_char")
+    cfg = char_cfg(g)
+    sd = R.leaf_state(g0_state(g))
+    ctx = R.Ctx(mode, masks=g0_masks(g) if mode == "train" else None)
+    out = R.forward_step(cfg, sd, g0_batch(g), torch.from_numpy(g[f"{mode}/eps"]), ctx)
+    for m in R.MOD_ORDER:
+        close(out["enc"][m][0], g[f"{mode}/enc/{m}/mu"])
+        close(out["enc"][m][1], g[f"{mode}/enc/{m}/logvar"])
+    close(out["latents"]["mus"], g[f"{mode}/mus"])
+    close(out["latents"]["joint"][0], g[f"{mode}/joint/mu"])
+    close(out["latents"]["individual_divs"], g[f"{mode}/individual_divs"])
+    close(out["rec"]["text"][:, ::16], g[f"{mode}/rec/text"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(checksums(out["rec"]["text"]), g[f"{mode}/recchk/text"], rtol=1e-4, atol=1e-3)
+    for k, v in out["log_probs"].items():
+        close(v, g[f"{mode}/log_probs/{k}"])
+    close(out["total_loss"], g[f"{mode}/total_loss"])
+    out["total_loss"].backward()
+    pre = f"{mode}/grad/"
+    names = [k[len(pre):] for k in g.files if k.startswith(pre)]
+    assert len(names) >= 380 and any("encoder_text.feature_extractor.resblock_8" in n for n in names)
+    for name in names:
+        ref = g[pre + name]
+        scale = max(np.abs(ref).max(), 1e-3)
+        if name.endswith(".bias") and (pre + name[:-4] + "weight") in g.files:
+            scale = max(scale, np.abs(g[pre + name[:-4] + "weight"]).max())
+        np.testing.assert_allclose(sd[name].grad.numpy(), ref, rtol=1e-3, atol=1e-3 * scale, err_msg=name)
+    assert not [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad and v.grad is None]
 
 
 def test_g1_config_c1():

@@ -18,7 +18,8 @@ from mimic_amd.ops import Bn, Geom, Mask, RES_A, RES_B
 OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_reduce", "block_out_bwd",
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
-            "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows"]
+            "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
+            "dense_logprob_rows"]
 
 
 def install(monkeypatch):
@@ -349,6 +350,14 @@ def token_nll_bwd(ids, g, shape, norm):
     return d
 
 
+def dense_nll_fwd(logp, target, norm):
+    return (-(torch.where(target != 0, target * logp, torch.zeros_like(logp)).double().sum()) / norm).float().reshape(1)
+
+
+def dense_nll_bwd(target, g, norm):
+    return -g / norm * target
+
+
 def laplace_logprob_rows(x_hat, target, scale):
     rows, tb = x_hat.shape[0], target.shape[0]
     tgt = target.reshape(tb, -1).repeat(rows // tb, 1)
@@ -359,6 +368,12 @@ def token_logprob_rows(logp, ids):
     rows, tb = logp.shape[0], ids.shape[0]
     idx = ids.long().repeat(rows // tb, 1)
     return logp.gather(-1, idx.unsqueeze(-1)).squeeze(-1).sum(dim=1)
+
+
+def dense_logprob_rows(logp, target):
+    rows, tb = logp.shape[0], target.shape[0]
+    tgt = target.reshape(tb, -1).repeat(rows // tb, 1)
+    return (tgt * logp.reshape(rows, -1)).sum(dim=1)
 
 
 def embedding_fwd(ids, table, out_dtype=None):
