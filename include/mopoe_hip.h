@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 8
+#define MOPOE_ABI_VERSION 9
 
 /* error codes */
 #define MOPOE_OK 0
@@ -115,6 +115,22 @@ int mopoe_conv_fwd(const float* x, const float* wp, const float* bias, float* y,
                    const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
                    double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
                    void* stream);
+
+/* conv2 of a residual block with the residual mix in its epilogue (ResidualBlocks.py:31-32,63-64,95-96,129-130:
+ * `out = self.a * residual + self.b * out`, residual = BN(shortcut conv), a = 2.0, b = 0.3 at every call site):
+ *   y = a * bn(s) + b * mask * (conv(act(x)) + bias),   out_stats += {sum, sumsq} of the stored y
+ * s: the shortcut conv's output, y's shape and storage type; bn: its BatchNorm (batch statistics complete, i.e. the
+ * shortcut conv was enqueued earlier on the same stream).  drop2(conv2(.)) is never written to memory.
+ * Needs the vector path (channel counts multiples of 4, 16-byte aligned tensors), else MOPOE_ERR_ARG. */
+typedef struct {
+  const void* s;
+  mopoe_bn_ref bn;
+  float a, b;
+} mopoe_mix_ref;
+int mopoe_conv_fwd_mix(const float* x, const float* wp, const float* bias, float* y, const mopoe_conv_geom* g,
+                       const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, const mopoe_mix_ref* mix,
+                       double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* dx = d(conv)/d(input) applied to dy.  If relu_bn.mode != 0 the ReLU that fed the conv is inverted in
  * the epilogue, dx *= [bn(xin) > 0], and bwd_sums (optional) += {sum dx, sum dx*xhat} per input channel
@@ -278,6 +294,10 @@ int mopoe_conv_fwd_bf16(const uint16_t* x, const uint16_t* wp, const float* bias
                         const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
                         double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
                         void* stream);
+int mopoe_conv_fwd_mix_bf16(const uint16_t* x, const uint16_t* wp, const float* bias, uint16_t* y,
+                            const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
+                            const mopoe_mix_ref* mix, double* out_stats, const mopoe_conv_plan* plan, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int mopoe_conv_dgrad_bf16(const uint16_t* dy, const uint16_t* wp, void* dx, int32_t dx_is_f32, const mopoe_conv_geom* g,
                           const mopoe_bn_ref* relu_bn, const uint16_t* xin, double* bwd_sums,
                           const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes, void* stream);

@@ -75,6 +75,8 @@ struct GemmArgs {
   float* partial;        // split-K: [nsplit][rows_total][Cn] raw partial sums (else nullptr)
   int* counters;         // vector path: one arrival counter per output tile of a split reduction (zero on entry, left zero)
   long rows_total;       // N*Hy*Wy
+  int mix;               // forward only (vector path): y = mix_a * bn(xin) + mix_b * mask * (conv + bias); relu_bn carries bn
+  float mix_a, mix_b;
 };
 
 // storage helpers of gemm_epilogue_rows.inc for this family: fp32 results and fp32 xin, rows of Cn floats; a lane's 8
@@ -198,7 +200,7 @@ void gather_gemm_kernel(const GemmArgs a) {
   const int kq = tid % KQ;
   const int trow = tid / KQ;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const bool do_relu_bn = a.relu_bn.mode != 0 && !a.mix;
   const int hw = a.Hq * a.Wq;
 
   // per-column epilogue constants and running column sums (persist across this block's M tiles)
@@ -226,7 +228,8 @@ void gather_gemm_kernel(const GemmArgs a) {
     for (int c = tid; c < BN; c += NT) {
       const int n = n0 + c;
       BnC k = BnC{0.f, 0.f, 0.f, 0.f};
-      if (n < a.Cn && do_relu_bn) k = bn_coef(a.relu_bn, n);
+      if (n < a.Cn && (do_relu_bn || a.mix)) k = bn_coef(a.relu_bn, n);
+      if (a.mix) { k.scale *= a.mix_a; k.shift *= a.mix_a; }
       epi[0][c] = k.mean; epi[1][c] = k.rstd; epi[2][c] = k.scale; epi[3][c] = k.shift;
       epi[4][c] = (n < a.Cn && a.bias) ? a.bias[n] : 0.f;
     }
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (TI * TJ >= 4 ? 3 : 4)) void direct
   }
 
   const int l31 = lane & 31, lhi = lane >> 5;
-  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const bool do_relu_bn = a.relu_bn.mode != 0 && !a.mix;
   const int hw = a.Hq * a.Wq;
 
   float cbias[TJ], s1[TJ], s2[TJ];
@@ -1037,7 +1040,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
                          int dest_on_small, int Ck, int Cn, int w_nk, const mopoe_bn_ref* bn_in,
                          const mopoe_mask_ref* mask, double* out_stats, const mopoe_bn_ref* relu_bn,
                          const float* xin, double* bwd_sums, const mopoe_conv_plan* plan, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const mopoe_mix_ref* mix = nullptr) {
   // the head of the workspace holds the arrival counters of in-kernel split reductions (kept zero by the kernels)
   int* counters = nullptr;
   if (ws && ws_bytes > WS_COUNTER_BYTES) { counters = (int*)ws; ws = (char*)ws + WS_COUNTER_BYTES; ws_bytes -= WS_COUNTER_BYTES; }
@@ -1073,11 +1076,18 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.out_stats = out_stats;
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
+  a.mix = 0; a.mix_a = a.mix_b = 0.f;
+  if (mix) {   // residual mix in the epilogue: the shortcut's BN rides in relu_bn, its tensor in xin (vector path only)
+    if (!mix->s || mix->bn.mode == 0 || relu_bn || xin) { set_error("conv_fwd_mix: needs s and its BatchNorm"); return MOPOE_ERR_ARG; }
+    if (!vec || !aligned16(mix->s)) { set_error("conv_fwd_mix: channel counts must be multiples of 4 and tensors 16-byte aligned"); return MOPOE_ERR_ARG; }
+    a.mix = 1; a.mix_a = mix->a; a.mix_b = mix->b;
+    a.relu_bn = mix->bn; a.xin = (const float*)mix->s;
+  }
   a.nsplit = 1; a.partial = nullptr; a.counters = nullptr;
   static const bool dbg_nostats = getenv("MOPOE_DEBUG_NOSTATS") != nullptr;  // timing experiments only
   if (dbg_nostats) { a.out_stats = nullptr; a.bwd_sums = nullptr; }
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
-  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
+  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !a.xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
   if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
   if (a.mask.kind == 1 && a.mask.rows_per_sample != a.Hy * a.Wy) { set_error("channel mask: rows_per_sample must be Hout*Wout"); return MOPOE_ERR_ARG; }
   if (a.rows_total >= (1L << 31) || (long)g->N * a.Hx * a.Wx >= (1L << 31)) { set_error("conv: more than 2^31 rows"); return MOPOE_ERR_ARG; }
@@ -1098,7 +1108,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     cfg = plan->tile;
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
     if ((cfg == 5 || cfg == 6) && Ck % 32 != 0) cfg -= 3;   // 5, 6 = tiles 2, 4 with a 32-deep K chunk
-    if (cfg >= 8 && (!vec || Ck % 8 != 0)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels
+    if (cfg >= 8 && (!vec || Ck % 8 != 0 || a.mix)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels
   }
   static const int TILE_BM[12] = {128, 256, 64, 256, 128, 64, 128, 128, 128, 256, 64, 128};
   static const int TILE_BN[12] = {128, 64, 64, 128, 64, 64, 64, 128, 128, 64, 64, 64};
@@ -1206,6 +1216,16 @@ extern "C" int mopoe_conv_fwd(const float* x, const float* wp, const float* bias
   // Conv: output on the small grid.  ConvTranspose: output on the big grid (phases).
   return launch_gather(x, wp, bias, y, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask, out_stats,
                        nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_fwd_mix(const float* x, const float* wp, const float* bias, float* y, const mopoe_conv_geom* g,
+                                  const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, const mopoe_mix_ref* mix,
+                                  double* out_stats, const mopoe_conv_plan* plan, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !wp || !y || !mix) { set_error("conv_fwd_mix: null pointer"); return MOPOE_ERR_ARG; }
+  return launch_gather(x, wp, bias, y, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask, out_stats,
+                       nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream, mix);
 }
 
 extern "C" int mopoe_conv_dgrad(const float* dy, const float* wp, float* dx, const mopoe_conv_geom* g,

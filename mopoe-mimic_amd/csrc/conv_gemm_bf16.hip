@@ -53,6 +53,8 @@ struct GemmArgsH {
   int* counters;         // split reduction: one arrival counter per output tile, zero on entry, left zero
   long rows_total;
   int out_f32;
+  int mix;               // forward only: y = mix_a * bn(xin) + mix_b * mask * (conv + bias); relu_bn carries that bn
+  float mix_a, mix_b;
 };
 
 // storage helpers of gemm_epilogue_rows.inc for this family: bf16 (or, on request, fp32) results, bf16 xin
@@ -168,14 +170,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   const int kq = tid & 3;            // 16-byte piece within a 64-byte tile row
   const int trow = tid >> 2;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const bool do_relu_bn = a.relu_bn.mode != 0;
+  const bool do_relu_bn = a.relu_bn.mode != 0 && !a.mix;
   const int hw = a.Hq * a.Wq;
 
   // epilogue constants per output column of this block (zero for columns past Cn)
   for (int c = tid; c < BN; c += NT) {
     const int n = n0 + c;
     BnC k = BnC{0.f, 0.f, 0.f, 0.f};
-    if (n < a.Cn && do_relu_bn) k = bn_coef(a.relu_bn, n);
+    if (n < a.Cn && (do_relu_bn || a.mix)) k = bn_coef(a.relu_bn, n);
+    if (a.mix) { k.scale *= a.mix_a; k.shift *= a.mix_a; }
     epi[0][c] = k.mean; epi[1][c] = k.rstd; epi[2][c] = k.scale; epi[3][c] = k.shift;
     epi[4][c] = (n < a.Cn && a.bias) ? a.bias[n] : 0.f;
   }
@@ -526,7 +529,8 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
                               const mopoe_conv_geom* g, int dest_on_small, int Ck, int Cn, int w_nk,
                               const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats,
                               const mopoe_bn_ref* relu_bn, const bf16_t* xin, double* bwd_sums,
-                              const mopoe_conv_plan* plan, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              const mopoe_conv_plan* plan, void* ws, size_t ws_bytes, hipStream_t stream,
+                              const mopoe_mix_ref* mix = nullptr) {
   GemmArgsH a;
   a.X = X; a.W = W; a.Y = Y; a.bias = bias; a.out_f32 = out_f32;
   a.N = g->N; a.Ck = Ck; a.Cn = Cn; a.Cin_w = g->Cin; a.Cout_w = g->Cout;
@@ -560,9 +564,15 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   a.out_stats = out_stats;
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
+  a.mix = 0; a.mix_a = a.mix_b = 0.f;
+  if (mix) {   // residual mix in the epilogue: the shortcut's BN rides in relu_bn, its (bf16) tensor in xin
+    if (!mix->s || mix->bn.mode == 0 || relu_bn || xin || out_f32 || !aligned16(mix->s)) { set_error("conv_fwd_mix_bf16: needs an aligned bf16 s, its BatchNorm and a bf16 result"); return MOPOE_ERR_ARG; }
+    a.mix = 1; a.mix_a = mix->a; a.mix_b = mix->b;
+    a.relu_bn = mix->bn; a.xin = (const bf16_t*)mix->s;
+  }
   a.nsplit = 1; a.partial = nullptr; a.counters = nullptr;
   if (a.bn_in.mode != 0 && (a.bn_in.C != Ck || Ck > MAX_BN_C)) { set_error("bn_in channel mismatch (%d vs %d)", a.bn_in.C, Ck); return MOPOE_ERR_ARG; }
-  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
+  if (a.relu_bn.mode != 0 && (a.relu_bn.C != Cn || !a.xin)) { set_error("relu_bn needs xin and C == %d", Cn); return MOPOE_ERR_ARG; }
   if (a.mask.kind != 0 && !a.mask.mask) { set_error("mask pointer missing"); return MOPOE_ERR_ARG; }
   if (a.mask.kind == 1 && a.mask.rows_per_sample != a.Hy * a.Wy) { set_error("channel mask: rows_per_sample must be Hout*Wout"); return MOPOE_ERR_ARG; }
   if (a.rows_total >= (1L << 31) || (long)g->N * a.Hx * a.Wx >= (1L << 31)) { set_error("conv: more than 2^31 rows"); return MOPOE_ERR_ARG; }
@@ -641,6 +651,16 @@ extern "C" int mopoe_conv_fwd_bf16(const uint16_t* x, const uint16_t* wp, const 
   if (!x || !wp || !y) { set_error("conv_fwd_bf16: null pointer"); return MOPOE_ERR_ARG; }
   return launch_gather_bf16(x, wp, bias, y, y_is_f32, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask,
                             out_stats, nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mopoe_conv_fwd_mix_bf16(const uint16_t* x, const uint16_t* wp, const float* bias, uint16_t* y,
+                                       const mopoe_conv_geom* g, const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask,
+                                       const mopoe_mix_ref* mix, double* out_stats, const mopoe_conv_plan* plan,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = validate_geom(g)) return rc;
+  if (!x || !wp || !y || !mix) { set_error("conv_fwd_mix_bf16: null pointer"); return MOPOE_ERR_ARG; }
+  return launch_gather_bf16(x, wp, bias, y, 0, g, g->transposed ? 0 : 1, g->Cin, g->Cout, /*w_nk=*/0, bn_in, mask,
+                            out_stats, nullptr, nullptr, nullptr, plan, workspace, workspace_bytes, (hipStream_t)stream, mix);
 }
 
 extern "C" int mopoe_conv_dgrad_bf16(const uint16_t* dy, const uint16_t* wp, void* dx, int32_t dx_is_f32,

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -47,6 +47,10 @@ class _BnRef(C.Structure):
 
 class _MaskRef(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("kind", C.c_int32), ("rows_per_sample", C.c_int32)]
+
+
+class _MixRef(C.Structure):   # mopoe_mix_ref
+    _fields_ = [("s", C.c_void_p), ("bn", _BnRef), ("a", C.c_float), ("b", C.c_float)]
 
 
 class _RunDesc(C.Structure):
@@ -433,15 +437,29 @@ def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int):
     return cands
 
 
+def conv_mix_supported(x, g: Geom) -> bool:
+    """can conv_fwd(..., mix=) take this layer?  (the residual mix lives in the vector path's row-major epilogue)"""
+    return _is16(x) or (g.Cin % 4 == 0 and g.Cout % 4 == 0)
+
+
 def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Optional[Mask] = None,
-             out_stats=None, out_dtype=None):
+             out_stats=None, out_dtype=None, mix=None):
     """out_dtype: dtype of the result (default: the activation operand's).  bf16 family: x bf16 + wp bf16 (the
-    weight copy); the single-channel image-side layers take the fp32 image / fp32 taps and a bf16 wide tensor."""
+    weight copy); the single-channel image-side layers take the fp32 image / fp32 taps and a bf16 wide tensor.
+    mix = (s, bn_s[, a, b]): the residual mix of a block in the epilogue, y = a * bn_s(s) + b * mask * (conv + bias)
+    (include/mopoe_hip.h: mopoe_conv_fwd_mix); out_stats are then those of y."""
     _dev(x, wp, bias, out_stats)
     assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
     out_dtype = out_dtype or x.dtype
     gc = g.c()
     stream = _stream()
+    mixr = None
+    if mix is not None:
+        ms, mbn = mix[0], mix[1]
+        _dev(ms)
+        assert tuple(ms.shape) == g.out_shape and ms.dtype == out_dtype and ms.is_contiguous() and conv_mix_supported(x, g)
+        mixc = _MixRef(ms.data_ptr(), mbn.c(), float(mix[2]) if len(mix) > 2 else RES_A, float(mix[3]) if len(mix) > 3 else RES_B)
+        mixr = C.byref(mixc)
     if _is16(x) or out_dtype == BF16:
         plain = bn_in is None and mask is None
         if not g.transposed and g.Cin == 1:      # image stem: fp32 pixels x fp32 taps -> bf16 features
@@ -462,10 +480,14 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
         bnr, mr, f32 = _bn(bn_in), _mask(mask), C.c_int32(int(out_dtype == torch.float32))
 
         def launch16(plan, stats=None):
+            if mixr is not None:
+                _check(lib().mopoe_conv_fwd_mix_bf16(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), bnr, mr, mixr, _p(stats),
+                                                     plan, _p(ws), C.c_size_t(nbytes), stream))
+                return
             _check(fn(_p(x), _p(wp), _p(bias), _p(y), f32, C.byref(gc), bnr, mr, _p(stats), plan, _p(ws),
                       C.c_size_t(nbytes), stream))
 
-        key = ("fwd16", g, bn_in is not None, mask is not None, out_stats is not None, out_dtype)
+        key = ("fwd16", g, bn_in is not None, mask is not None, out_stats is not None, out_dtype) + (("mix",) if mix is not None else ())
         plan = _tuned_plan(key, lambda: _gather_candidates_bf16("fwd", g, nbytes),
                            lambda ref: launch16(ref, _scratch_like(out_stats)))
         launch16(plan, out_stats)
@@ -476,10 +498,14 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
     bnr, mr = _bn(bn_in), _mask(mask)
 
     def launch(plan, stats=None):
+        if mixr is not None:
+            _check(lib().mopoe_conv_fwd_mix(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), bnr, mr, mixr, _p(stats), plan,
+                                            _p(ws), C.c_size_t(nbytes), stream))
+            return
         _check(fn(_p(x), _p(wp), _p(bias), _p(y), C.byref(gc), bnr, mr, _p(stats), plan, _p(ws), C.c_size_t(nbytes),
                   stream))
 
-    key = ("fwd", g, bn_in is not None, mask is not None, out_stats is not None)
+    key = ("fwd", g, bn_in is not None, mask is not None, out_stats is not None) + (("mix",) if mix is not None else ())
     plan = _tuned_plan(key, lambda: _gather_candidates("fwd", g, nbytes),
                        lambda ref: launch(ref, _scratch_like(out_stats)))
     launch(plan, out_stats)

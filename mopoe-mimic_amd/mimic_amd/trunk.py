@@ -5,8 +5,9 @@ expressed as launches of the HIP ops (mimic_amd.ops).  One chain serves all four
 Reference semantics (mimic/networks/ResidualBlocks.py:20-33,51-65,84-97,118-131):
     main(x)  = drop2(conv2(relu(bn2(drop1(conv1(relu(bn1(x))))))))
     out      = 2.0 * BN_s(conv_s(x)) + 0.3 * main(x)
-What is materialised per block in HBM: d1 = drop1(conv1(.)), m = drop2(conv2(.)), s = conv_s(x), out.
-BN -> ReLU is applied while the next conv loads its operand; BN statistics are accumulated by the
+What is materialised per block in HBM: d1 = drop1(conv1(.)), s = conv_s(x), out -- the residual mix happens in the
+epilogue of conv2 (ops.conv_fwd(mix=)), so m = drop2(conv2(.)) exists only for channel counts the vector path
+cannot take.  BN -> ReLU is applied while the next conv loads its operand; BN statistics are accumulated by the
 epilogue of the kernel that produces the tensor.
 """
 from __future__ import annotations
@@ -72,6 +73,7 @@ class MaskSource:
 # optimizer), so they are launched on a second HIP stream: on the deep / 1-D layers, whose grids cannot fill 256
 # CUs, the wgrad kernels then run concurrently with the dgrad / BatchNorm-backward chain instead of after it.
 WGRAD_SIDE_STREAM = os.environ.get("MOPOE_WGRAD_STREAM", "1") != "0"
+FUSE_MIX = os.environ.get("MOPOE_FUSE_MIX", "1") != "0"   # residual mix in conv2's epilogue (A/B switch)
 FUSE_NEXT_REDUCE = os.environ.get("MOPOE_FUSE_NEXT_REDUCE", "1") != "0"
 LANES = os.environ.get("MOPOE_LANES", "0,1").split(",")   # 0 = weight gradients, 1 = projection-shortcut branch
 LANES_IN_CAPTURE = os.environ.get("MOPOE_LANES_IN_CAPTURE", "0") != "0"   # (tests/tools/capture_probe_torch.py)
@@ -192,13 +194,16 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         rps_out = rows_out // batch
         if dropout:
             mask2 = masks.get(spec.name + ".dropout2", batch, rps_out, g2.Cout, spec.twod, x.device)
-        m = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
-        lane.join()
+        lane.join()   # the shortcut's statistics are complete: its BatchNorm enters conv2's epilogue
         bns = _bn(sbn, training, st_s, rows_out)
         if training:
             running.append((st_s, sbn, rows_out))
         st_out = arena.take(g2.Cout)
-        out = ops.block_out_fwd(s, m, bns, out_stats=st_out)
+        if FUSE_MIX and ops.conv_mix_supported(d1, g2):
+            out = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2, mix=(s, bns), out_stats=st_out)
+        else:
+            m = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
+            out = ops.block_out_fwd(s, m, bns, out_stats=st_out)
         saved.append(dict(x=x, d1=d1, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2))
         x, x_stats = out, st_out
     return x, saved, running

@@ -306,13 +306,14 @@ def _resblock(sd, prefix, x, ctx: Ctx, *, stride, pad, transposed, twod, short_n
     else:
         convf = F.conv_transpose1d if transposed else F.conv1d
     # ctx.bf16: x arrives rounded (it is a stored tensor); the conv operands relu(bn(.)) and the weights are rounded
-    # for the MFMA; d1 = drop1(conv1), m = drop2(conv2), s = conv_s and the block output are stored tensors
+    # for the MFMA; d1 = drop1(conv1), s = conv_s and the block output are stored tensors (drop2(conv2) is consumed by
+    # the residual mix in conv2's epilogue, in fp32)
     h = _q(F.relu(_bn(sd, prefix + ".bn1", x, ctx)), ctx)
     h = convf(h, _qw(sd[prefix + ".conv1.weight"], ctx), sd.get(prefix + ".conv1.bias"))
     h = _q(_drop(h, prefix + ".dropout1", ctx, twod), ctx)
     h = _q(F.relu(_bn(sd, prefix + ".bn2", h, ctx)), ctx)
     h = convf(h, _qw(sd[prefix + ".conv2.weight"], ctx), sd.get(prefix + ".conv2.bias"), stride=stride, padding=pad)
-    h = _q(_drop(h, prefix + ".dropout2", ctx, twod), ctx)
+    h = _drop(h, prefix + ".dropout2", ctx, twod)
     s = _q(convf(x, _qw(sd[prefix + f".{short_name}.0.weight"], ctx), sd[prefix + f".{short_name}.0.bias"],
                  stride=stride, padding=pad), ctx)
     s = _bn(sd, prefix + f".{short_name}.1", s, ctx)

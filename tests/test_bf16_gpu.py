@@ -91,6 +91,19 @@ def _conv_case(name, g: Geom, plan=None):
         check16(f"{name}/fwd_fused_bn{mode}", y, y_ref, atol_rel=1.5e-3)
         # statistics are sums over the STORED values: a result that rounds the other way moves them by one step of one element
         check(f"{name}/fwd_fused_bn{mode}/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
+    # residual mix in the epilogue (mopoe_conv_fwd_mix_bf16): y = 2 bn_s(s) + 0.3 mask (conv + bias)
+    for mode in (1, 2):
+        bn = make_bn(g.Cin, rows_in, mode, gen, x.float() if mode == 1 else None)
+        sres = torch.randn(g.out_shape, generator=gen).to(BF)
+        bns = make_bn(g.Cout, rows_out, mode, gen, sres.float() if mode == 1 else None)
+        cmask = Mask((torch.rand(g.N, g.Cout, generator=gen) < 0.5).float() * 2, 1, rps_out)
+        st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref, mix=(sres, bns))
+        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+        y = ops.conv_fwd(xd, wd, g, bn_in=to_dev(bn), bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st,
+                         mix=(sres.to(DEV), to_dev(bns)))
+        check16(f"{name}/fwd_mix_bn{mode}", y, y_ref, atol_rel=1.5e-3)
+        check(f"{name}/fwd_mix_bn{mode}/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
     emask = Mask((torch.rand(g.out_shape, generator=gen) < 0.5).float() * 2, 2, rps_out)
     check16(f"{name}/fwd_emask", ops.conv_fwd(xd, wd, g, bias=bias.to(DEV), mask=to_dev(emask)),
             TB.conv_fwd(x, wp, g, bias=bias, mask=emask))

@@ -177,11 +177,26 @@ def test_conv_every_launch_plan(name, g):
     dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
     dw_ref = TB.conv_wgrad(x, dy, g, bn_in=bn)
     xd, wd, dyd, bnd = x.to(DEV), wp.to(DEV), dy.to(DEV), to_dev(bn)
+    # residual mix in conv2's epilogue (mopoe_conv_fwd_mix): vector-path shapes only
+    mixable = ops.conv_mix_supported(xd, g)
+    assert mixable == (g.Cin % 4 == 0 and g.Cout % 4 == 0)
+    if mixable:
+        sres = torch.randn(g.out_shape, generator=gen)
+        bns = make_bn(g.Cout, rows_out, 1, gen, sres)
+        stm_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        ym_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=stm_ref, mix=(sres, bns))
+        sresd, bnsd = sres.to(DEV), to_dev(bns)
     for tile in range(12):
         for split in (1, 2, 5, 16):
             with ops.force_plan(tile, split):
                 st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
                 y = ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st)
+                if mixable:
+                    stm = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                    ym = ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bias.to(DEV), mask=to_dev(cmask), out_stats=stm,
+                                      mix=(sresd, bnsd))
+                    check(f"plan/{name}/t{tile}s{split}/fwd_mix", ym, ym_ref)
+                    check(f"plan/{name}/t{tile}s{split}/fwd_mix_stats", stm, stm_ref, rtol=1e-4, atol_rel=1e-4)
                 s = torch.zeros(2, g.Cin, dtype=torch.float64, device=DEV)
                 dx = ops.conv_dgrad(dyd, wd, g, relu_bn=bnd, xin=xd, bwd_sums=s)
             tag = f"plan/{name}/t{tile}s{split}"

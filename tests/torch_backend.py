@@ -19,7 +19,7 @@ OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_red
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
-            "dense_logprob_rows"]
+            "dense_logprob_rows", "conv_mix_supported"]
 
 
 def install(monkeypatch):
@@ -107,7 +107,11 @@ def _act16(x, bn):
 
 
 # ---- convolution family ------------------------------------------------------------------------
-def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None, out_dtype=None):
+def conv_mix_supported(x, g: Geom) -> bool:
+    return x.dtype == BF16 or (g.Cin % 4 == 0 and g.Cout % 4 == 0)
+
+
+def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None, out_dtype=None, mix=None):
     assert tuple(x.shape) == g.in_shape and tuple(wp.shape) == (g.taps, g.Cin, g.Cout)
     out_dtype = out_dtype or x.dtype
     if g.transposed and g.Cout == 1 and x.dtype == BF16:
@@ -120,6 +124,10 @@ def conv_fwd(x, wp, g: Geom, bn_in=None, bias=None, mask=None, out_stats=None, o
     mm = _mask_mult(y, mask)
     if mm is not None:
         y = y * mm
+    if mix is not None:   # residual mix in the epilogue: drop2(conv2) itself is never stored (nor rounded)
+        a, b = (mix[2], mix[3]) if len(mix) > 3 else (RES_A, RES_B)
+        _, _, scale, shift = bn_coef(mix[1])
+        y = a * (_f(mix[0]) * scale + shift) + b * y
     if out_dtype == BF16:
         y = _q16(y)
     _accum(out_stats, y)
