@@ -151,10 +151,12 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
                       rtol=3e-4, atol_rel=3e-4)
 
 
-def test_edge_layers_bf16():
-    """image stem / head with the wide tensor in bf16 (fp32 pixels, taps and tap gradients)"""
+@pytest.mark.parametrize("n,hs,ws", [(2, 16, 16), (3, 5, 16), (2, 6, 6)], ids=["b2_16x16", "b3_5x16_partial_tile", "b2_6x6_streaming"])
+def test_edge_layers_bf16(n, hs, ws):
+    """image stem / head with the wide tensor in bf16 (fp32 pixels, taps and tap gradients): MFMA forms (C = 64, rows of
+    16 k pixels) and the streaming kernels"""
     gen = torch.Generator().manual_seed(5)
-    gs = Geom(2, 16, 16, 32, 32, 1, 64, 3, 3, 2, 2, 1, 1, False)
+    gs = Geom(n, hs, ws, 2 * hs, 2 * ws, 1, 64, 3, 3, 2, 2, 1, 1, False)
     img = torch.rand(gs.in_shape, generator=gen)
     w = torch.randn(9, 1, 64, generator=gen) / 3
     st_ref = torch.zeros(2, 64, dtype=torch.float64)
@@ -164,7 +166,7 @@ def test_edge_layers_bf16():
     check("stem/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
     dy = torch.randn(gs.out_shape, generator=gen).to(BF)
     check("stem/wgrad", ops.conv_wgrad(img.to(DEV), dy.to(DEV), gs), TB.conv_wgrad(img, dy, gs), rtol=3e-4, atol_rel=3e-4)
-    gh = Geom(2, 16, 16, 32, 32, 64, 1, 3, 3, 2, 2, 1, 1, True)
+    gh = Geom(n, hs, ws, 2 * hs, 2 * ws, 64, 1, 3, 3, 2, 2, 1, 1, True)
     x = torch.randn(gh.in_shape, generator=gen).to(BF)
     wh = torch.randn(9, 64, 1, generator=gen) / 8
     b = torch.tensor([0.3])

@@ -71,6 +71,8 @@ GEOMS = [
     ("enc_k4s4p1_16to4", Geom(2, 4, 4, 16, 16, 64, 80, 4, 4, 4, 4, 1, 1, False)),
     ("enc_1x1_128", Geom(2, 16, 16, 16, 16, 128, 128, 1, 1, 1, 1, 0, 0, False)),
     ("stem_k3s2_cin1", Geom(2, 16, 16, 32, 32, 1, 64, 3, 3, 2, 2, 1, 1, False)),
+    ("stem_k3s2_cin1_ragged_rows", Geom(3, 5, 16, 10, 32, 1, 64, 3, 3, 2, 2, 1, 1, False)),   # 240 pixels: partial MFMA tile
+    ("stem_k3s2_cin1_c32", Geom(2, 8, 8, 16, 16, 1, 32, 3, 3, 2, 2, 1, 1, False)),              # C != 64: streaming kernels
     ("linear_320to128", Geom(7, 1, 1, 1, 1, 320, 128, 1, 1, 1, 1, 0, 0, False)),
     ("tiny_c4_k4s2p1", Geom(4, 16, 16, 32, 32, 4, 8, 4, 4, 2, 2, 1, 1, False)),
     ("tiny_c20_k4s2p0", Geom(4, 1, 1, 4, 4, 16, 20, 4, 4, 2, 2, 0, 0, False)),
@@ -81,6 +83,7 @@ GEOMS = [
     ("dec_k4_from1x1", Geom(5, 1, 1, 4, 4, 320, 256, 4, 4, 4, 4, 0, 0, True)),
     ("dec_1x1", Geom(2, 8, 8, 8, 8, 192, 192, 1, 1, 1, 1, 0, 0, True)),
     ("dec_head_k3s2p1op1_cout1", Geom(2, 16, 16, 32, 32, 64, 1, 3, 3, 2, 2, 1, 1, True)),
+    ("dec_head_k3s2p1op1_ragged_rows", Geom(3, 5, 16, 10, 32, 64, 1, 3, 3, 2, 2, 1, 1, True)),
     ("tiny_dec_c8_k4s2p1", Geom(4, 4, 4, 8, 8, 8, 4, 4, 4, 2, 2, 1, 1, True)),
     ("text_convT1d_k4s2p1", Geom(3, 1, 16, 1, 32, 640, 512, 1, 4, 1, 2, 0, 1, True)),
     ("text_convT1d_from1", Geom(4, 1, 1, 1, 4, 640, 640, 1, 4, 1, 4, 0, 0, True)),
