@@ -251,7 +251,7 @@ _conv_calls = 0
 _plans = {}
 _GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128),
                  (128, 128), (256, 64), (64, 64), (128, 64))   # 8..11: the LDS-free kernel
-_SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)
+_SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128)
 
 
 _forced_plan = None

@@ -58,6 +58,7 @@ def main():
         fused = "+bn" if (k.get("bn_in") is not None or k.get("relu_bn") is not None) else ""
         fused += "+st" if k.get("out_stats") is not None else ""
         fused += "+m" if k.get("mask") is not None else ""
+        fused += "+mix" if k.get("mix") is not None else ""
         groups.setdefault((name, fused, g), []).append((a, k))
     rows = []
     for (name, fused, g), lst in groups.items():
@@ -79,7 +80,7 @@ def main():
         if is16:
             od = k.get("out_dtype") or next(x for x in a if torch.is_tensor(x)).dtype
             flags = flags + ((od,) if kind != "wgrad" else ())
-        plan = ops.plan_table().get((kind + ("16" if is16 else ""), g) + flags)
+        plan = ops.plan_table().get((kind + ("16" if is16 else ""), g) + flags + (("mix",) if k.get("mix") is not None else ()))
         rows.append((us * len(lst) / 1e3, len(lst), us, name + fused + f" {plan}", g, flops(name, g)))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows); totfl = sum(r[5] * r[1] for r in rows)
