@@ -82,11 +82,17 @@ struct GemmArgs {
 // storage helpers of gemm_epilogue_rows.inc for this family: fp32 results and fp32 xin, rows of Cn floats; a lane's 8
 // columns are two float4 halves, the upper one may lie past Cn (Cn % 4 == 0 on the vector path)
 __device__ __forceinline__ float epi_round(const GemmArgs&, float x) { return x; }
-__device__ __forceinline__ void epi_xin8(const GemmArgs& a, long yrow, int ncol, bool ok_hi, float (&xi)[8]) {
+struct EpiXinRaw { float4 lo, hi; };
+constexpr bool EPI_PREFETCH_XIN = false;
+__device__ __forceinline__ EpiXinRaw epi_xin_ld(const GemmArgs& a, long yrow, int ncol, bool ok_hi) {
   const float* p = a.xin + yrow * a.Cn + ncol;
-  const float4 lo = *reinterpret_cast<const float4*>(p);
-  const float4 hi = ok_hi ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; xi[3] = lo.w; xi[4] = hi.x; xi[5] = hi.y; xi[6] = hi.z; xi[7] = hi.w;
+  EpiXinRaw r;
+  r.lo = *reinterpret_cast<const float4*>(p);
+  r.hi = ok_hi ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+__device__ __forceinline__ void epi_xin_unpack(const EpiXinRaw& r, float (&xi)[8]) {
+  xi[0] = r.lo.x; xi[1] = r.lo.y; xi[2] = r.lo.z; xi[3] = r.lo.w; xi[4] = r.hi.x; xi[5] = r.hi.y; xi[6] = r.hi.z; xi[7] = r.hi.w;
 }
 __device__ __forceinline__ void epi_store8(const GemmArgs& a, long yrow, int ncol, bool ok_hi, const float (&v)[8]) {
   float* dst = a.Y + yrow * a.Cn + ncol;

@@ -59,8 +59,12 @@ struct GemmArgsH {
 
 // storage helpers of gemm_epilogue_rows.inc for this family: bf16 (or, on request, fp32) results, bf16 xin
 __device__ __forceinline__ float epi_round(const GemmArgsH& a, float x) { return a.out_f32 ? x : round_bf16(x); }
-__device__ __forceinline__ void epi_xin8(const GemmArgsH& a, long yrow, int ncol, bool /*ok_hi*/, float (&xi)[8]) {
-  const uint4 xu = *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
+typedef uint4 EpiXinRaw;
+constexpr bool EPI_PREFETCH_XIN = false;   // measured on C3 / C5: requesting xin ahead of the transposition costs registers, -4 % (rejected)
+__device__ __forceinline__ EpiXinRaw epi_xin_ld(const GemmArgsH& a, long yrow, int ncol, bool /*ok_hi*/) {
+  return *reinterpret_cast<const uint4*>(a.xin + yrow * a.ldy + ncol);
+}
+__device__ __forceinline__ void epi_xin_unpack(const EpiXinRaw& xu, float (&xi)[8]) {
   xi[0] = bf16_lo(xu.x); xi[1] = bf16_hi(xu.x); xi[2] = bf16_lo(xu.y); xi[3] = bf16_hi(xu.y);
   xi[4] = bf16_lo(xu.z); xi[5] = bf16_hi(xu.z); xi[6] = bf16_lo(xu.w); xi[7] = bf16_hi(xu.w);
 }

@@ -14,13 +14,66 @@ from __future__ import annotations
 
 from typing import Iterable, Iterator, Tuple
 
+import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
 
+def resize_u8(imgs: torch.Tensor, size: int) -> torch.Tensor:
+    """uint8 [n, H, W] -> uint8 [n, size, size] with PIL's bicubic filter, the reference's per-sample transform
+    (dataio/utils.py:30-34: ToPILImage -> Resize(BICUBIC) -> ToTensor) applied once; identity when the size matches"""
+    if imgs.shape[-2:] == (size, size):
+        return imgs.contiguous()
+    from PIL import Image
+    out = torch.empty(imgs.shape[0], size, size, dtype=torch.uint8)
+    for i in range(imgs.shape[0]):
+        im = Image.fromarray(imgs[i].numpy(), mode="L").resize((size, size), Image.BICUBIC)
+        out[i] = torch.from_numpy(np.asarray(im).copy())
+    return out
+
+
+def get_transform_img(args, img_clf_type: str = "resnet", clf_training: bool = False):
+    """per-sample image transform of the reference (dataio/utils.py:27-39): uint8 [H, W] -> float [1, S, S] in [0, 1]
+    through PIL's bicubic resize.  (torchvision is not needed: ToPILImage / ToTensor of a single-channel uint8 image are a
+    reshape and a division by 255.)"""
+    if clf_training:
+        raise NotImplementedError("classifier transforms are outside the hot path")
+    size = int(args.img_size)
+
+    def transform(x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != torch.uint8:
+            raise TypeError("the .pt image tensors hold uint8 pixels")
+        return resize_u8(x.unsqueeze(0), size).float().div(255.0)
+
+    return transform
+
+
+def get_undersample_indices(labels_df):
+    count_class_1 = labels_df[labels_df == 1].count().sum()
+    df_class_0 = labels_df[labels_df == 0]
+    df_class_1 = labels_df[labels_df == 1].dropna(how="all").fillna(0)
+    df_class_0_under = df_class_0.sample(count_class_1)
+    return [*df_class_1.index.to_list(), *df_class_0_under.index.to_list()]
+
+
+def filter_labels(labels, which_labels, undersample_dataset: bool, split: str):
+    """drop the rows whose label is the "uncertain" class -1 (reference dataio/utils.py:153-176)"""
+    indices = []
+    for cl in which_labels:
+        indices += labels.index[(labels[cl] == -1)].tolist()
+    labels = labels.drop(list(set(indices)))
+    if undersample_dataset and split == "train":
+        labels = labels[labels.index.isin(get_undersample_indices(labels))]
+    return labels
+
+
+def get_str_labels(binary_labels):
+    return ["Finding"] if binary_labels else ["Lung Opacity", "Pleural Effusion", "Support Devices"]
+
+
 def get_data_loaders(args, dataset, which_set: str = "train", weighted_sampler: bool = False, nbr_samples_4_sampler: int = -1):
     if weighted_sampler:
-        raise NotImplementedError("label-weighted sampling needs the MIMIC label tables (outside the hot path)")
+        raise NotImplementedError("label-weighted sampling is used by the classifier training only (outside the hot path)")
     workers = int(getattr(args, "dataloader_workers", 0))
     if getattr(args, "distributed", False):
         sampler = torch.utils.data.distributed.DistributedSampler(dataset)

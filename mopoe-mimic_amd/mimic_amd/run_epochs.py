@@ -453,18 +453,33 @@ def run_epochs(rank, exp) -> typing.List[dict]:
             set_up_process_group(args.world_size, _rank_of(rank))
         reducer = GradAllReducer(exp.mm_vae, args.world_size)
         reducer.broadcast_parameters()
-    train_sampler, train_loader = get_data_loaders(args, exp.dataset_train, which_set="train",
-                                                   weighted_sampler=getattr(args, "weighted_sampler", False))
-    test_sampler, test_loader = get_data_loaders(args, exp.dataset_test, which_set="eval")
+    from .dataio.MimicDataset import DeviceResidentMimic, Mimic
+    resident = (isinstance(exp.dataset_train, Mimic) and args.device.type == "cuda"
+                and getattr(args, "device_resident_data", True) and not getattr(args, "weighted_sampler", False))
+    if resident:
+        # a real split lives in HBM (uint8 images + token ids): batches are gathered on the device with
+        # DistributedSampler's index rule, no worker processes and no per-step PCIe traffic (dataio.DeviceResidentMimic)
+        ws, rk = (args.world_size, _rank_of(rank)) if getattr(args, "distributed", False) else (1, 0)
+        train_loader = DeviceResidentMimic(exp.dataset_train, args.device, args.batch_size, True, rk, ws, args.seed)
+        test_loader = DeviceResidentMimic(exp.dataset_test, args.device, args.batch_size, True, rk, ws, args.seed)
+    else:
+        train_sampler, train_loader = get_data_loaders(args, exp.dataset_train, which_set="train",
+                                                       weighted_sampler=getattr(args, "weighted_sampler", False))
+        test_sampler, test_loader = get_data_loaders(args, exp.dataset_test, which_set="eval")
     callbacks = Callbacks(exp)
     history = []
     for epoch in range(getattr(args, "start_epoch", 0), args.end_epoch):
         end = time.time()
-        samplers_set_epoch(args, train_sampler, test_sampler, epoch)
-        tr = train(exp, PrefetchToDevice(train_loader, args.device), reducer)
+        if resident:
+            train_loader.set_epoch(epoch)
+            test_loader.set_epoch(epoch)
+            tr = train(exp, train_loader, reducer)
+        else:
+            samplers_set_epoch(args, train_sampler, test_sampler, epoch)
+            tr = train(exp, PrefetchToDevice(train_loader, args.device), reducer)
         if reducer is not None:
             reducer.sync_buffers()       # running statistics are per rank during training; rank 0's are evaluated / saved
-        test_results = test(epoch, exp, PrefetchToDevice(test_loader, args.device))
+        test_results = test(epoch, exp, test_loader if resident else PrefetchToDevice(test_loader, args.device))
         history.append({"epoch": epoch, "train": tr, "test": test_results, "seconds": time.time() - end})
         if callbacks.update_epoch(epoch, test_results, time.time() - end):
             break

@@ -32,6 +32,7 @@ def default_flags(**overrides) -> argparse.Namespace:
         # (evaluated only when the caller passes no device: a launcher process must not initialise the GPU)
         device=overrides["device"] if "device" in overrides else torch.device("cuda" if torch.cuda.is_available() else "cpu"),
         start_epoch=0, end_epoch=1, eval_freq=10, world_size=1, dataloader_workers=0, weighted_sampler=False,
+        dir_data=".", word_min_occ=3, undersample_dataset=False, binary_labels=False,   # real tensor datasets (dataio.Mimic)
         compute_dtype="fp32",   # 'bf16': bf16 storage + bf16 MFMA with fp32 accumulation (BASELINE configs #3, #5)
         mm_vae_save="mm_vae", start_early_stopping_epoch=0, max_early_stopping_index=5, testing_batches=2,
         encoder_save_m1="encoderM1", encoder_save_m2="encoderM2", encoder_save_m3="encoderM3",
@@ -43,12 +44,18 @@ def default_flags(**overrides) -> argparse.Namespace:
     return f
 
 
+from ..dataio.utils import get_str_labels  # noqa: E402
+
+
 class HotPathExperiment:
     """Carries exactly what run_epochs.basic_routine_epoch / train read from the experiment object."""
 
     def __init__(self, flags):
         self.flags = flags
         self.dataset = flags.dataset
+        self.labels = get_str_labels(getattr(flags, "binary_labels", False))
+        # (the datasets come first, as in the reference: a real split sets flags.vocab_size / num_features for the networks)
+        self.dataset_train, self.dataset_test = self.set_dataset()
         self.modalities = self.set_modalities()
         self.num_modalities = len(self.modalities)
         self.subsets = self.set_subsets()
@@ -56,15 +63,17 @@ class HotPathExperiment:
         self.optimizer = None
         self.rec_weights = self.set_rec_weights()
         self.style_weights = {"PA": flags.beta_m1_style, "Lateral": flags.beta_m2_style, "text": flags.beta_m3_style}
-        self.dataset_train, self.dataset_test = self.set_dataset()
 
     def set_dataset(self):
-        """mimic/utils/experiment.py:106-123: dataset 'testing' = the synthetic Mimic_testing pair; the real MIMIC-CXR
-        tensor files are absent from the reference checkout."""
-        from ..dataio.MimicDataset import Mimic_testing
-        if self.flags.dataset != "testing":
-            raise NotImplementedError("only dataset='testing' (synthetic Mimic_testing) is available to the hot path")
-        return Mimic_testing(self.flags), Mimic_testing(self.flags)
+        """mimic/utils/experiment.py:94-111: dataset 'testing' = the synthetic Mimic_testing pair (vocab_size 3517); anything
+        else = the tensor files under flags.dir_data (splits 'train' and 'eval'), which also set flags.vocab_size."""
+        from ..dataio.MimicDataset import Mimic, Mimic_testing
+        if self.flags.dataset == "testing":
+            self.flags.vocab_size = getattr(self.flags, "vocab_size", 3517)
+            return Mimic_testing(self.flags), Mimic_testing(self.flags)
+        if getattr(self.flags, "only_text_modality", False):
+            raise NotImplementedError("the text-only model (VAETextMimic) is out of scope (SURVEY 2.1-8)")
+        return Mimic(self.flags, self.labels, split="train"), Mimic(self.flags, self.labels, split="eval")
 
     def set_modalities(self):
         f = self.flags

@@ -9,6 +9,17 @@ from ..mmvae import mixture_row_starts, reweight_weights  # noqa: F401
 from .exceptions import NaNInLatent
 
 
+def get_alphabet(alphabet_path=None):
+    """the character set of text_encoding='char' (reference utils.py:166-169 reads mimic/alphabet.json, a JSON list of
+    characters; the file is not part of the reference checkout, so its path comes from flags.alphabet_path)"""
+    import json
+    if not alphabet_path or not os.path.exists(alphabet_path):
+        raise FileNotFoundError("text_encoding='char' on real reports needs flags.alphabet_path = path of alphabet.json "
+                                "(a JSON list of characters containing '$', '&' and '@')")
+    with open(alphabet_path) as f:
+        return str("".join(json.load(f)))
+
+
 def reparameterize(mu, logvar):
     """z = mu + eps * exp(logvar / 2).  The training path never calls this: the fused latent kernel
     produces z.  Kept for API parity with evaluation callers (plain torch on the tensors' device)."""

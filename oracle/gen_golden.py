@@ -14,6 +14,7 @@ Fixtures:
   g2_edges.npz           mixture partition for B in {7,8,32,56,63,64,65,256}, partial-modality inference
   g3_traj.npz            3 Adam steps of losses (train_nodrop)
   g5_char.npz            text_encoding='char' (char_encoding networks, dense categorical likelihood): as g0
+  g6_dataset.npz         the reference's Mimic / MimicSentences dataset classes on small synthetic tensor files
 Usage:  python oracle/gen_golden.py [--only g0_s64 ...]
 """
 from __future__ import annotations
@@ -471,6 +472,44 @@ def gen_g4(run_epochs):
     return store
 
 
+def gen_g6_dataset(run_epochs):
+    """The reference's tensor dataset classes (mimic/dataio/MimicDataset.py: Mimic :23-128, MimicSentences :224-396,
+    filter_labels dataio/utils.py:153-176) on the synthetic files tests/golden_util.make_mimic_files writes: kept label rows,
+    vocabulary (order, min_occ rule, specials), encoded sentences, what __getitem__ returns for every index.
+    nltk is absent here: `word_tokenize` is replaced by str.split, which the files are written for (lower-case words and
+    punctuation separated by single spaces: nltk yields the same tokens).  torchvision is absent: the reference dataset is
+    built with transform_images=False (raw uint8 images come back), so the fixture pins everything but the PIL resize."""
+    import json
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_util import make_mimic_files
+    import mimic.dataio.MimicDataset as MD
+    MD.word_tokenize = lambda line: line.split()
+    store = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        make_mimic_files(tmp, img_size=16, n_train=40, n_eval=12, seed=3)
+        for min_occ in (3, 14):
+            args = SimpleNamespace(dir_data=tmp, img_size=16, text_encoding="word", len_sequence=12, word_min_occ=min_occ,
+                                   undersample_dataset=False, feature_extractor_img="resnet")
+            labels = ["Lung Opacity", "Pleural Effusion", "Support Devices"]
+            for split in ("train", "eval"):
+                ds = MD.Mimic(args, labels, split=split, transform_images=False)
+                pre = f"occ{min_occ}/{split}/"
+                store[pre + "kept_rows"] = np.asarray(ds.labels.index, dtype=np.int64)
+                store[pre + "vocab_size"] = np.array(args.vocab_size)
+                store[pre + "w2i_json"] = np.frombuffer(json.dumps(ds.report_findings_dataset.get_w2i(), sort_keys=True).encode(), dtype=np.uint8)
+                text, lab, pa0 = [], [], []
+                for i in range(len(ds)):
+                    sample, label = ds[i]
+                    text.append(sample["text"].numpy())
+                    lab.append(label.numpy())
+                    pa0.append(int(sample["PA"][0, 0]) * 256 + int(sample["Lateral"][1, 2]))
+                store[pre + "text"] = np.stack(text).astype(np.float32)
+                store[pre + "label"] = np.stack(lab).astype(np.float32)
+                store[pre + "pixel_probe"] = np.asarray(pa0, dtype=np.int64)
+    return store
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -491,6 +530,7 @@ def main():
         "g3_traj": lambda: gen_g3(run_epochs),
         "g4_likelihood": lambda: gen_g4(run_epochs),
         "g5_char": lambda: gen_g5_char(run_epochs),
+        "g6_dataset": lambda: gen_g6_dataset(run_epochs),
     }
     for name, job in jobs.items():
         if args.only and name not in args.only:

@@ -47,3 +47,37 @@ def checksums(t: torch.Tensor):
     t = t.detach().double().flatten().cpu()
     idx = torch.linspace(0, t.numel() - 1, 16).long()
     return np.concatenate([[t.sum().item(), (t * t).sum().item()], t[idx].numpy()])
+
+
+def make_mimic_files(dir_data, img_size=16, n_train=40, n_eval=12, seed=3):
+    """A small MIMIC-CXR-shaped dataset on disk (the layout reference mimic/dataio/MimicDataset.py:35-44 reads):
+    <dir_data>/files_small_<img_size>/{train,eval}_{pa,lat}.pt (uint8 [n, S, S]), *_findings.csv, *_labels.csv.
+    Sentences are drawn from a fixed word list and written lower-case with space-separated punctuation, so every
+    tokeniser (nltk's, a whitespace split, the product's fallback) yields the same tokens; some labels are the
+    "uncertain" class -1 or empty.  Deterministic in `seed`: the golden generator and the tests build identical files."""
+    import os
+    import numpy as np
+    import pandas as pd
+    import torch
+    rng = np.random.RandomState(seed)
+    words = ("the heart is normal in size lungs are clear no pleural effusion or pneumothorax seen there mild "
+             "cardiomegaly stable support devices place opacity left right lower lobe consolidation atelectasis small "
+             "unchanged compared prior exam").split()
+    d = os.path.join(dir_data, f"files_small_{img_size}")
+    os.makedirs(d, exist_ok=True)
+    for split, n in (("train", n_train), ("eval", n_eval)):
+        torch.save(torch.from_numpy(rng.randint(0, 256, (n, img_size, img_size)).astype(np.uint8)), os.path.join(d, f"{split}_pa.pt"))
+        torch.save(torch.from_numpy(rng.randint(0, 256, (n, img_size, img_size)).astype(np.uint8)), os.path.join(d, f"{split}_lat.pt"))
+        sents = []
+        for _ in range(n):
+            k = rng.randint(3, 22)
+            toks = [words[i] for i in rng.randint(0, len(words), k)]
+            for pos in sorted(rng.randint(1, k, rng.randint(0, 3)), reverse=True):
+                toks.insert(pos, ",")
+            sents.append(" ".join(toks + ["."]))
+        pd.DataFrame({"findings": sents}).to_csv(os.path.join(d, f"{split}_findings.csv"), index=False)
+        lab = rng.choice([0.0, 1.0, -1.0, np.nan], size=(n, 3), p=[0.5, 0.3, 0.08, 0.12])
+        lab[0] = [1.0, 0.0, 1.0]   # (both classes present whatever the draw)
+        pd.DataFrame(lab, columns=["Lung Opacity", "Pleural Effusion", "Support Devices"]).to_csv(
+            os.path.join(d, f"{split}_labels.csv"), index=False)
+    return d

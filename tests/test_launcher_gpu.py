@@ -39,3 +39,31 @@ def test_two_epochs_through_the_launcher(tmp_path):
                    "epoch1_samples_per_sec": hist[1]["train"]["samples_per_sec"],
                    "epoch1_seconds": hist[1]["train"]["seconds"]}, f)
     assert hist[1]["train"]["samples_per_sec"] > 0
+
+
+def test_two_epochs_on_tensor_files_through_the_launcher(tmp_path):
+    """dataset != 'testing': the reference's file layout (mimic/dataio/MimicDataset.py:35-44) read by dataio.Mimic, the
+    vocabulary of the training split sizing the text networks, the splits resident in HBM (dataio.DeviceResidentMimic):
+    captured steps for full batches, the eager step for the short last batch of an epoch."""
+    from golden_util import make_mimic_files
+    from mimic_amd import main_mimic as MM
+    data = tmp_path / "data"
+    make_mimic_files(str(data), img_size=64, n_train=100, n_eval=30, seed=5)
+    run_dir = tmp_path / "run"
+    flags = MM.parse_flags(["--dataset", "mimic", "--dir_data", str(data), "--img_size", "64", "--class_dim", "32",
+                            "--DIM_img", "64", "--DIM_text", "32", "--batch_size", "8", "--len_sequence", "128",
+                            "--end_epoch", "2", "--initial_learning_rate", "1e-5", "--dir_experiment_run", str(run_dir)])
+    m = MM.Main(flags)
+    m.setup_distributed = lambda: (setattr(m.flags, "world_size", 1), setattr(m.flags, "distributed", False))
+    assert m.main() is True and m.current_tries == 0
+    hist = m.history
+    n_train = hist[0]["train"]["steps"]
+    assert n_train >= 8 and [h["epoch"] for h in hist] == [0, 1]
+    # every full batch after the capture's set-up step replays the graph; a short last batch runs eagerly
+    assert hist[1]["train"]["graphed_steps"] >= n_train - 1
+    for h in hist:
+        assert all(v == v and abs(v) < 1e9 for v in h["train"]["last"].values()) and "total_loss" in h["test"]
+    sd = torch.load(run_dir / "checkpoints" / "0001" / "mm_vae", map_location="cpu")
+    vocab = sd["decoder_text.text_generator.generator.6.bias"].numel()
+    assert 30 < vocab < 60, vocab          # the synthetic reports' vocabulary (+ 3 specials), not the default 3517
+    assert sd["encoder_text.feature_extractor.embedding.weight"].shape[0] == vocab
