@@ -720,7 +720,7 @@ struct WgradArgs {
   int vecI, vecJ;
   unsigned x_bytes, dy_bytes;   // operand sizes for the buffer descriptors (vector path)
   int fast;          // 1: every 16-pixel K chunk is a run inside one image row, or whole rows of one image
-  mopoe_bn_ref bn_in;
+  mopoe_bn_ref bn_in;  int xcd_remap;         // 1: XCD-aware block numbering (gemm_common.hpp: xcd_swizzle)
 };
 
 // SPEC: 0 = mode flags at run time; 1 / 2 = fast pixel addressing without / with BN+ReLU on x (see gather_gemm_kernel)
@@ -741,11 +741,18 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
-  const int it_i = blockIdx.x / a.nJ, it_j = blockIdx.x % a.nJ;
+  // logical block id: x = channel tile, y = tap fastest, z = pixel chunk slowest, each XCD owning a contiguous range of it:
+  // every block of one pixel chunk (all taps, all channel tiles) then reads its activation / gradient rows through ONE L2
+  const unsigned lin = a.xcd_remap ? xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                                 gridDim.x * gridDim.y * gridDim.z)
+                                   : blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned bx = lin % gridDim.x, byz = lin / gridDim.x;
+  const unsigned by = byz % gridDim.y, bz = byz / gridDim.y;
+  const int it_i = bx / a.nJ, it_j = bx % a.nJ;
   const int i0 = it_i * BI, j0 = it_j * BJ;
-  const int tap = blockIdx.y;
+  const int tap = by;
   const int ky = tap / a.kw, kx = tap % a.kw;
-  const long mbeg = (long)blockIdx.z * a.chunk;
+  const long mbeg = (long)bz * a.chunk;
   const long mend = mbeg + a.chunk < a.Ms ? mbeg + a.chunk : a.Ms;
   const int total = (int)((mend - mbeg + BK - 1) / BK);
 
@@ -1296,6 +1303,8 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   split = (a.Ms + chunk - 1) / chunk;
   a.chunk = chunk;
   a.atomic = split > 1;
+  static const bool xcd_remap = !getenv("MOPOE_NO_XCD_REMAP");   // (A/B switch)
+  a.xcd_remap = xcd_remap ? 1 : 0;
   const size_t bytes = (size_t)taps * g->Cin * g->Cout * sizeof(float);
   if (a.atomic && !dwp_is_zero) {
     if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }

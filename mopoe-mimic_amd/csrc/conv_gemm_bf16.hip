@@ -362,7 +362,7 @@ struct WgradArgsH {
   int atomic;
   unsigned x_bytes, dy_bytes;
   int lg_ws, lg_hw;      // log2 of Ws and Hs*Ws (POW2 kernels)
-  mopoe_bn_ref bn_in;
+  mopoe_bn_ref bn_in;  int xcd_remap;         // 1: XCD-aware block numbering (gemm_common.hpp: xcd_swizzle)
 };
 
 template <int BI, int BJ, bool XFORM, bool POW2>
@@ -381,11 +381,18 @@ __global__ __launch_bounds__(256) void wgrad_gemm_bf16_kernel(const WgradArgsH a
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
-  const int it_i = blockIdx.x / a.nJ, it_j = blockIdx.x % a.nJ;
+  // logical block id: x = channel tile, y = tap fastest, z = pixel chunk slowest, each XCD owning a contiguous range of it:
+  // every block of one pixel chunk (all taps, all channel tiles) then reads its activation / gradient rows through ONE L2
+  const unsigned lin = a.xcd_remap ? xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                                 gridDim.x * gridDim.y * gridDim.z)
+                                   : blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned bx = lin % gridDim.x, byz = lin / gridDim.x;
+  const unsigned by = byz % gridDim.y, bz = byz / gridDim.y;
+  const int it_i = bx / a.nJ, it_j = bx % a.nJ;
   const int i0 = it_i * BI, j0 = it_j * BJ;
-  const int tap = blockIdx.y;
+  const int tap = by;
   const int ky = tap / a.kw, kx = tap % a.kw;
-  const long mbeg = (long)blockIdx.z * a.chunk;
+  const long mbeg = (long)bz * a.chunk;
   const long mend = mbeg + a.chunk < a.Ms ? mbeg + a.chunk : a.Ms;
   const int total = (int)((mend - mbeg + BKH - 1) / BKH);
 
@@ -722,6 +729,8 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   split = (a.Ms + chunk - 1) / chunk;
   a.chunk = chunk;
   a.atomic = split > 1;
+  static const bool xcd_remap = !getenv("MOPOE_NO_XCD_REMAP");   // (A/B switch)
+  a.xcd_remap = xcd_remap ? 1 : 0;
   const size_t bytes = (size_t)taps * g->Cin * g->Cout * sizeof(float);
   if (a.atomic && !dwp_is_zero) {
     if (hipMemsetAsync(dwp, 0, bytes, stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }

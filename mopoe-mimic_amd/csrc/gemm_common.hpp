@@ -74,4 +74,14 @@ static inline int validate_geom(const mopoe_conv_geom* g) {
   return 0;
 }
 
+
+// XCD-aware block numbering.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one L2:
+// MI355X_MICROARCH.md, Workgroup dispatch): the logical id returned here gives each XCD a CONTIGUOUS range of the grid,
+// so blocks that read the same operand panels (all taps / channel tiles of one pixel chunk of a weight gradient) fill
+// one L2 instead of eight.  Bijective for any grid size (cdna_hip_programming.md T1); a pure speed choice.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned orig, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+}
+
 }  // namespace mopoe
