@@ -77,6 +77,7 @@ struct GemmArgs {
   long rows_total;       // N*Hy*Wy
   int mix;               // forward only (vector path): y = mix_a * bn(xin) + mix_b * mask * (conv + bias); relu_bn carries bn
   float mix_a, mix_b;
+  int xcd_remap;         // 1: XCD-aware block numbering
 };
 
 // storage helpers of gemm_epilogue_rows.inc for this family: fp32 results and fp32 xin, rows of Cn floats; a lane's 8
@@ -172,9 +173,20 @@ void gather_gemm_kernel(const GemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int n0 = blockIdx.y * BN;
-  const int phase = blockIdx.z / a.nsplit;
-  const int split = blockIdx.z - phase * a.nsplit;
+  // XCD-aware logical block (gemm_common.hpp: xcd_swizzle): each XCD owns a contiguous range of M-tile groups together with
+  // ALL their column tiles, phases and splits -- the blocks that gather the same activation rows fill one L2, not eight
+  unsigned lbx = blockIdx.x, lby = blockIdx.y, lbz = blockIdx.z;
+  if (a.xcd_remap) {
+    const unsigned inner = gridDim.y * gridDim.z;
+    const unsigned sw = xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * inner);
+    lbx = sw / inner;
+    const unsigned rem = sw - lbx * inner;
+    lby = rem % gridDim.y;
+    lbz = rem / gridDim.y;
+  }
+  const int n0 = lby * BN;
+  const int phase = lbz / a.nsplit;
+  const int split = lbz - phase * a.nsplit;
 
   const TapWalk tw = tap_walk(a, phase);
   const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
@@ -264,7 +276,7 @@ void gather_gemm_kernel(const GemmArgs a) {
   }
 
   const long nMt = (a.rows_per_phase + BM - 1) / BM;
-  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+  for (long mt = lbx; mt < nMt; mt += gridDim.x) {
     const long m0 = mt * BM;
 
     // ---- per-thread A rows -------------------------------------------------------------------------
@@ -537,9 +549,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (TI * TJ >= 4 ? 3 : 4)) void direct
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int n0 = blockIdx.y * BN;
-  const int phase = blockIdx.z / a.nsplit;
-  const int split = blockIdx.z - phase * a.nsplit;
+  // XCD-aware logical block (gemm_common.hpp: xcd_swizzle): each XCD owns a contiguous range of M-tile groups together with
+  // ALL their column tiles, phases and splits -- the blocks that gather the same activation rows fill one L2, not eight
+  unsigned lbx = blockIdx.x, lby = blockIdx.y, lbz = blockIdx.z;
+  if (a.xcd_remap) {
+    const unsigned inner = gridDim.y * gridDim.z;
+    const unsigned sw = xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * inner);
+    lbx = sw / inner;
+    const unsigned rem = sw - lbx * inner;
+    lby = rem % gridDim.y;
+    lbz = rem / gridDim.y;
+  }
+  const int n0 = lby * BN;
+  const int phase = lbz / a.nsplit;
+  const int split = lbz - phase * a.nsplit;
 
   const TapWalk tw = tap_walk(a, phase);
   const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
@@ -583,7 +606,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (TI * TJ >= 4 ? 3 : 4)) void direct
   }
 
   const long nMt = (a.rows_per_phase + BM - 1) / BM;
-  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+  for (long mt = lbx; mt < nMt; mt += gridDim.x) {
     const long m0 = mt * BM;
     int ry0[TI], rx0[TI], rbase[TI];
     bool rvalid[TI];
@@ -1090,6 +1113,8 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
   a.mix = 0; a.mix_a = a.mix_b = 0.f;
+  static const bool xcd_remap_g = !getenv("MOPOE_NO_XCD_REMAP");   // (A/B switch)
+  a.xcd_remap = xcd_remap_g ? 1 : 0;
   if (mix) {   // residual mix in the epilogue: the shortcut's BN rides in relu_bn, its tensor in xin (vector path only)
     if (!mix->s || mix->bn.mode == 0 || relu_bn || xin) { set_error("conv_fwd_mix: needs s and its BatchNorm"); return MOPOE_ERR_ARG; }
     if (!vec || !aligned16(mix->s)) { set_error("conv_fwd_mix: channel counts must be multiples of 4 and tensors 16-byte aligned"); return MOPOE_ERR_ARG; }

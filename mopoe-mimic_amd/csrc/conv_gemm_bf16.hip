@@ -55,6 +55,7 @@ struct GemmArgsH {
   int out_f32;
   int mix;               // forward only: y = mix_a * bn(xin) + mix_b * mask * (conv + bias); relu_bn carries that bn
   float mix_a, mix_b;
+  int xcd_remap;         // 1: XCD-aware block numbering
 };
 
 // storage helpers of gemm_epilogue_rows.inc for this family: bf16 (or, on request, fp32) results, bf16 xin
@@ -146,9 +147,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int n0 = blockIdx.y * BN;
-  const int phase = blockIdx.z / a.nsplit;
-  const int split = blockIdx.z - phase * a.nsplit;
+  // XCD-aware logical block (gemm_common.hpp: xcd_swizzle): each XCD owns a contiguous range of M-tile groups together with
+  // ALL their column tiles, phases and splits -- the blocks that gather the same activation rows fill one L2, not eight
+  unsigned lbx = blockIdx.x, lby = blockIdx.y, lbz = blockIdx.z;
+  if (a.xcd_remap) {
+    const unsigned inner = gridDim.y * gridDim.z;
+    const unsigned sw = xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * inner);
+    lbx = sw / inner;
+    const unsigned rem = sw - lbx * inner;
+    lby = rem % gridDim.y;
+    lbz = rem / gridDim.y;
+  }
+  const int n0 = lby * BN;
+  const int phase = lbz / a.nsplit;
+  const int split = lbz - phase * a.nsplit;
 
   const TapWalk tw = tap_walk(a, phase);
   const int nty = tw.nty, ntx = tw.ntx, ky0 = tw.ky0, kx0 = tw.kx0, kstep_y = tw.kstep_y, kstep_x = tw.kstep_x;
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
   }
 
   const long nMt = (a.rows_per_phase + BM - 1) / BM;
-  for (long mt = blockIdx.x; mt < nMt; mt += gridDim.x) {
+  for (long mt = lbx; mt < nMt; mt += gridDim.x) {
     const long m0 = mt * BM;
 
     int ry0[A_PER_THR], rx0[A_PER_THR], rbase[A_PER_THR];
@@ -576,6 +588,8 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   a.relu_bn = relu_bn ? *relu_bn : none;
   a.xin = xin; a.bwd_sums = bwd_sums;
   a.mix = 0; a.mix_a = a.mix_b = 0.f;
+  static const bool xcd_remap_g = !getenv("MOPOE_NO_XCD_REMAP");   // (A/B switch)
+  a.xcd_remap = xcd_remap_g ? 1 : 0;
   if (mix) {   // residual mix in the epilogue: the shortcut's BN rides in relu_bn, its (bf16) tensor in xin
     if (!mix->s || mix->bn.mode == 0 || relu_bn || xin || out_f32 || !aligned16(mix->s)) { set_error("conv_fwd_mix_bf16: needs an aligned bf16 s, its BatchNorm and a bf16 result"); return MOPOE_ERR_ARG; }
     a.mix = 1; a.mix_a = mix->a; a.mix_b = mix->b;
