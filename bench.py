@@ -227,6 +227,18 @@ def main():
     samples = bsz * world * args.steps
     value = samples / elapsed
 
+    # host cost of ONE step call with an idle queue in front of it (outside the timed region).  The time the host needs
+    # to enqueue K back-to-back steps (host_enqueue_ms_per_step) mostly measures back-pressure from the GPU queue: it
+    # tracks the GPU's step time whatever the host's own cost is.
+    host_call = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        run(1, start=args.warmup + args.steps + i)
+        host_call.append((host_done[0] - th) * 1e3)
+    fence()
+    host_call_ms = sorted(host_call)[1]
+
     roofline = None
     if not args.no_roofline:
         # second pass of the same steps, eager and on ONE stream, with HIP events around every implicit-GEMM launch:
@@ -248,7 +260,10 @@ def main():
         all_by = sum(v[3] for v in prof.values())
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-            with open(os.path.join(REPO, "profiles", "latest_pmc_hbm.json")) as f:
+            pmc_file = os.path.join(REPO, "profiles", f"latest_pmc_hbm_{args.config}.json")
+            if not os.path.exists(pmc_file):
+                pmc_file = os.path.join(REPO, "profiles", "latest_pmc_hbm.json")   # (config c2)
+            with open(pmc_file) as f:
                 pm = json.load(f)["kernels"]
             hit = pm.get(name)
             if hit:
@@ -300,6 +315,7 @@ def main():
                                    + ", BatchNorm batch stats + dropout, Adam",
                        "global_batch": bsz * world, "parallelism": f"dp{world}",
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),
+                       "host_ms_per_step_call_idle_queue": round(host_call_ms, 3),
                        "host_enqueue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
                        "model_tflops": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12, 2),
                        ("model_frac_of_bf16_mfma_peak" if cdtype == "bf16" else "model_frac_of_fp32_mfma_peak"):

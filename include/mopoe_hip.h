@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 9
+#define MOPOE_ABI_VERSION 10
 
 /* error codes */
 #define MOPOE_OK 0
@@ -191,7 +191,7 @@ typedef struct {
 int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_t n, float momentum, void* stream);
 
 /* column sums of a [rows, C] matrix into float out[C] (overwritten). */
-int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream);
+int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, int32_t out_is_zero, void* stream);
 
 /* ---- latent space ----------------------------------------------------------------------------------
  * One kernel for BaseMMVae.inference's subset loop (mimic/utils/BaseMMVae.py:148-177), mm_div.poe
@@ -311,7 +311,7 @@ int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dwp, con
 int mopoe_edge_expand_bf16(const float* scal, const float* w, uint16_t* out, const mopoe_conv_geom* g, int32_t C,
                            double* stats, void* stream);
 int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, const mopoe_conv_geom* g, int32_t C,
-                          void* stream);
+                          int32_t dw_is_zero, void* stream);
 int mopoe_edge_reduce_bf16(const uint16_t* x, const float* w, const float* bias, float* out, const mopoe_conv_geom* g,
                            int32_t C, void* stream);
 /* residual-block glue on bf16 tensors (same arithmetic in fp32 registers; results rounded once when stored) */
@@ -326,7 +326,7 @@ int mopoe_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_
                             int32_t C, const mopoe_bn_ref* bn, const double* sums, const mopoe_mask_ref* mask,
                             float* dgamma, float* dbeta, float* colsum_dx, const uint16_t* next_s,
                             const mopoe_bn_ref* next_bn, double* next_sums, void* stream);
-int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, void* stream);
+int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, int32_t out_is_zero, void* stream);
 /* embedding with a bf16 activation: out[r, :] = bf16(table[ids[r], :]) (fp32 table); backward scatter-adds the bf16
  * gradient rows into the fp32 dtable (overwritten), skipping padding_idx */
 /* log-softmax backward with the gradient written as bf16 (it enters the vocabulary head's GEMMs as a bf16 operand);

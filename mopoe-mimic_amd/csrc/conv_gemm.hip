@@ -1285,9 +1285,9 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   if (!x || !dy || !dwp) { set_error("conv_wgrad: null pointer"); return MOPOE_ERR_ARG; }
   hipStream_t stream = (hipStream_t)stream_;
   if ((!bn_in || bn_in->mode == 0) && !g->transposed && g->Cin == 1 && edge_supported(g, g->Cout, {dy, dwp}))
-    return edge_wgrad(dy, x, dwp, g, g->Cout, stream);
+    return edge_wgrad(dy, x, dwp, g, g->Cout, stream, dwp_is_zero != 0);
   if ((!bn_in || bn_in->mode == 0) && g->transposed && g->Cout == 1 && edge_supported(g, g->Cin, {x, dwp}))
-    return edge_wgrad(x, dy, dwp, g, g->Cin, stream);
+    return edge_wgrad(x, dy, dwp, g, g->Cin, stream, dwp_is_zero != 0);
   WgradArgs a;
   a.Xs = x; a.Dy = dy; a.dW = dwp;
   a.N = g->N; a.Hs = g->Hs; a.Ws = g->Ws; a.Hb = g->Hb; a.Wb = g->Wb; a.Cin = g->Cin; a.Cout = g->Cout;

@@ -774,11 +774,11 @@ extern "C" int mopoe_edge_expand_bf16(const float* scal, const float* w, uint16_
   if (!scal || !w || !out || !edge_supported(g, C, {w, out})) { set_error("edge_expand_bf16: needs k3 s2, C %% 4 == 0, aligned tensors"); return MOPOE_ERR_ARG; }
   return edge_expand<bf16_t>(scal, w, out, g, C, stats, (hipStream_t)stream);
 }
-extern "C" int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, const mopoe_conv_geom* g, int32_t C,
+extern "C" int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, const mopoe_conv_geom* g, int32_t C, int32_t dw_is_zero,
                                      void* stream) {
   if (int rc = validate_geom(g)) return rc;
   if (!vec || !scal || !dw || !edge_supported(g, C, {vec, dw})) { set_error("edge_wgrad_bf16: needs k3 s2, C %% 4 == 0, aligned tensors"); return MOPOE_ERR_ARG; }
-  return edge_wgrad<bf16_t>(vec, scal, dw, g, C, (hipStream_t)stream);
+  return edge_wgrad<bf16_t>(vec, scal, dw, g, C, (hipStream_t)stream, dw_is_zero != 0);
 }
 extern "C" int mopoe_edge_reduce_bf16(const uint16_t* x, const float* w, const float* bias, float* out,
                                       const mopoe_conv_geom* g, int32_t C, void* stream) {

@@ -479,10 +479,10 @@ int edge_expand(const float* scal, const float* W, T* out, const mopoe_conv_geom
 }
 
 template <typename T>
-int edge_wgrad(const T* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st) {
+int edge_wgrad(const T* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st, bool dw_is_zero) {
   const EdgeGeom eg = edge_geom(g, C);
   const long rows = (long)g->N * g->Hs * g->Ws;
-  if (hipMemsetAsync(dW, 0, sizeof(float) * 9 * C, st) != hipSuccess) { set_error("edge_wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
+  if (!dw_is_zero && hipMemsetAsync(dW, 0, sizeof(float) * 9 * C, st) != hipSuccess) { set_error("edge_wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
   static const bool use_mfma = !getenv("MOPOE_EDGE_VALU");
   if (use_mfma && C == 64 && g->Ws % 16 == 0 && vec_ok(C, {vec}, 8)) {
     static const int wg_blocks = ew_env("MOPOE_EDGE_WGRAD_BLOCKS", EDGE_MFMA_BLOCKS);
@@ -523,8 +523,8 @@ int edge_reduce(const T* x, const float* W, const float* bias, float* out, const
 
 template int edge_expand<float>(const float*, const float*, float*, const mopoe_conv_geom*, int, double*, hipStream_t);
 template int edge_expand<bf16_t>(const float*, const float*, bf16_t*, const mopoe_conv_geom*, int, double*, hipStream_t);
-template int edge_wgrad<float>(const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
-template int edge_wgrad<bf16_t>(const bf16_t*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
+template int edge_wgrad<float>(const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t, bool);
+template int edge_wgrad<bf16_t>(const bf16_t*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t, bool);
 template int edge_reduce<float>(const float*, const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
 template int edge_reduce<bf16_t>(const bf16_t*, const float*, const float*, float*, const mopoe_conv_geom*, int, hipStream_t);
 

@@ -329,10 +329,10 @@ static int bn_bwd_apply_t(const T* dy, const T* x, const T* add, T* dx, int64_t 
 }
 
 template <typename T>
-static int colsum_t(const T* x, float* out, int64_t rows, int32_t C, void* stream) {
+static int colsum_t(const T* x, float* out, int64_t rows, int32_t C, int32_t out_is_zero, void* stream) {
   EW_ARGCHECK(x && out && rows > 0 && C > 0, "colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
+  if (!out_is_zero && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
   int rc;
   constexpr int W = EwVec<T>::wide;
   if (ew_wide_ok<T>(C, {x}, "colsum", &rc))
@@ -404,9 +404,9 @@ extern "C" int mopoe_bn_running_update(const mopoe_bn_running_desc* desc, int32_
   return MOPOE_OK;
 }
 
-extern "C" int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, void* stream) {
-  return colsum_t<float>(x, out, rows, C, stream);
+extern "C" int mopoe_colsum(const float* x, float* out, int64_t rows, int32_t C, int32_t out_is_zero, void* stream) {
+  return colsum_t<float>(x, out, rows, C, out_is_zero, stream);
 }
-extern "C" int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, void* stream) {
-  return colsum_t<bf16_t>(x, out, rows, C, stream);
+extern "C" int mopoe_colsum_bf16(const uint16_t* x, float* out, int64_t rows, int32_t C, int32_t out_is_zero, void* stream) {
+  return colsum_t<bf16_t>(x, out, rows, C, out_is_zero, stream);
 }

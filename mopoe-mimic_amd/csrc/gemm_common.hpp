@@ -12,7 +12,7 @@ namespace mopoe {
 // edge.hip: streaming kernels for the single-channel image-side layers (T = storage type of the wide tensor)
 bool edge_supported(const mopoe_conv_geom* g, int C, std::initializer_list<const void*> ptrs);
 template <typename T> int edge_expand(const float* scal, const float* W, T* out, const mopoe_conv_geom* g, int C, double* stats, hipStream_t st);
-template <typename T> int edge_wgrad(const T* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st);
+template <typename T> int edge_wgrad(const T* vec, const float* scal, float* dW, const mopoe_conv_geom* g, int C, hipStream_t st, bool dw_is_zero = false);
 template <typename T> int edge_reduce(const T* x, const float* W, const float* bias, float* out, const mopoe_conv_geom* g, int C, hipStream_t st);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

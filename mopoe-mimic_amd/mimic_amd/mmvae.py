@@ -124,7 +124,8 @@ class _LatentFuse(torch.autograd.Function):
                 j += 2
         outs = ops.latent_fwd(mu_in, lv_in, eps, row_start, w, norm)
         ctx.args = (mu_in, lv_in, eps, row_start, w, norm, present)
-        return outs
+        ctx.set_materialize_grads(False)   # outputs the loss never touches arrive as None (the kernel takes null
+        return outs                        # pointers), not as five zero-filled tensors per step
 
     @staticmethod
     def backward(ctx, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd):

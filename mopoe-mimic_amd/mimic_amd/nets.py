@@ -20,8 +20,8 @@ import torch.nn as nn
 from . import ops
 from .layout import Bf16Weights, BnParams, Indexed, PackedConv, ResBlockParams, param_epoch
 from .ops import Geom
-from .trunk import (BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed, trunk_backward,
-                    trunk_forward)
+from .trunk import (BackwardArena, BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed,
+                    trunk_backward, trunk_forward)
 
 
 def _lin_geom(cin, cout):
@@ -69,6 +69,18 @@ class _HipNet(nn.Module):
     """Shared plumbing: parameter ordering, mask source, running-stat updates, bf16 weight copies."""
 
     mask_source: MaskSource = MaskSource()
+
+    def _misc_numel(self) -> int:
+        """floats a backward needs for the gradients OUTSIDE the residual trunk (stem / head / compressor / linear layers):
+        generously, every parameter of the network that is not a trunk parameter"""
+        n = getattr(self, "_misc_numel_cache", None)
+        if n is None:
+            trunk = set()
+            for spec in self.blocks:
+                trunk.update(id(p) for p in spec.params.parameters())
+            n = sum(p.numel() + 4 for p in self.parameters() if id(p) not in trunk)
+            object.__setattr__(self, "_misc_numel_cache", n)
+        return n
     dropout_enabled = True  # tests switch this off to reproduce the 'train_nodrop' fixtures
     act_dtype = torch.float32
     _shadow = None
@@ -154,17 +166,18 @@ def _compress_fwd(comp: _Compressor, feat, batch, w=lambda m: m.weight):
     return mu.view(batch, -1), lv.view(batch, -1), g
 
 
-def _compress_bwd(comp: _Compressor, feat, g, gmu, glv, grads, prefix, w=lambda m: m.weight):
+def _compress_bwd(comp: _Compressor, feat, g, gmu, glv, grads, prefix, w=lambda m: m.weight, arena=None):
     batch = feat.shape[0]
     dfeat = None
+    take = (lambda shape: arena.take_misc(shape)) if arena is not None else (lambda shape: None)
     for name, mod, gg in (("content_mu", comp.content_mu, gmu), ("content_logvar", comp.content_logvar, glv)):
         if gg is None:
             continue
         gg4 = gg.reshape(batch, 1, 1, -1)
-        grads[f"{prefix}.{name}.bias"] = ops.colsum(gg4)
+        grads[f"{prefix}.{name}.bias"] = ops.colsum(gg4, out=take((gg4.shape[-1],)))
         if feat.dtype != gg4.dtype:      # bf16 family: the gradient enters the GEMMs as a bf16 operand
             gg4 = gg4.to(feat.dtype)
-        grads[f"{prefix}.{name}.weight"] = ops.conv_wgrad(feat, gg4, g)
+        grads[f"{prefix}.{name}.weight"] = ops.conv_wgrad(feat, gg4, g, out=take((g.taps, g.Cin, g.Cout)))
         d = ops.conv_dgrad(gg4, w(mod), g, out_dtype=torch.float32)   # the two halves are summed in fp32, stored once
         dfeat = d if dfeat is None else dfeat.add_(d)
     return dfeat if dfeat is None or dfeat.dtype == feat.dtype else dfeat.to(feat.dtype)
@@ -216,9 +229,11 @@ class EncoderImg(_HipNet):
 
     def _run_backward(self, sv, in_needs_grad, gmu, glv):
         grads: Dict[str, torch.Tensor] = {}
-        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w)
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w)
-        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["x"], g0, sv["gs"])
+        ar = BackwardArena(self.blocks, sv["feat"].device, extra=self._misc_numel())
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w, ar)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w, ar)
+        gs = sv["gs"]
+        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["x"], g0, gs, out=ar.take_misc((gs.taps, gs.Cin, gs.Cout)))
         gx = None
         if in_needs_grad[0]:
             if self._bf16():
@@ -313,12 +328,14 @@ class DecoderImg(_HipNet):
         g4 = gimg.reshape(b, gimg.shape[2], gimg.shape[3], 1) if gimg.shape[1] == 1 \
             else gimg.permute(0, 2, 3, 1).contiguous()
         k = len(self.blocks)
-        grads[f"img_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], g4, sv["gh"])
-        grads[f"img_generator.generator.{k}.bias"] = ops.colsum(g4)
+        ar = BackwardArena(self.blocks, gimg.device, extra=self._misc_numel())
+        gh, gl = sv["gh"], sv["gl"]
+        grads[f"img_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], g4, gh, out=ar.take_misc((gh.taps, gh.Cin, gh.Cout)))
+        grads[f"img_generator.generator.{k}.bias"] = ops.colsum(g4, out=ar.take_misc((g4.shape[-1],)))
         dht = ops.conv_dgrad(g4, self.head.weight, sv["gh"], out_dtype=self.act_dtype)
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
-        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
-        grads["feature_generator.bias"] = ops.colsum(g0)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w, ar)
+        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, gl, out=ar.take_misc((gl.taps, gl.Cin, gl.Cout)))
+        grads["feature_generator.bias"] = ops.colsum(g0, out=ar.take_misc((g0.shape[-1],)))
         gz = ops.conv_dgrad(g0, self._w(self.feature_generator), sv["gl"], out_dtype=torch.float32).view(b, -1) \
             if in_needs_grad[0] else None
         return [gz], grads, arena
@@ -409,10 +426,12 @@ class EncoderText(_HipNet):
     def _run_backward(self, sv, in_needs_grad, gmu, glv):
         grads: Dict[str, torch.Tensor] = {}
         fe = self.feature_extractor
-        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w)
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w)
-        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, sv["gs"])
-        grads["feature_extractor.conv1.bias"] = ops.colsum(g0)
+        ar = BackwardArena(self.blocks, sv["feat"].device, extra=self._misc_numel())
+        dfeat = _compress_bwd(self.feature_compressor, sv["feat"], sv["gl"], gmu, glv, grads, "feature_compressor", self._w, ar)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dfeat, grads, self._w, ar)
+        gs = sv["gs"]
+        grads["feature_extractor.conv1.weight"] = ops.conv_wgrad(sv["emb"], g0, gs, out=ar.take_misc((gs.taps, gs.Cin, gs.Cout)))
+        grads["feature_extractor.conv1.bias"] = ops.colsum(g0, out=ar.take_misc((g0.shape[-1],)))
         if self.char:
             gx = ops.conv_dgrad(g0, self._w(fe.conv1), sv["gs"]).view(sv["ids"].shape) if in_needs_grad[0] else None
             return [gx], grads, arena
@@ -554,11 +573,12 @@ class DecoderText(_HipNet):
     def _run_backward(self, sv, in_needs_grad, glogp):
         grads: Dict[str, torch.Tensor] = {}
         b = glogp.shape[0]
-        gh = sv["gh"]
+        gh, gl = sv["gh"], sv["gl"]
+        ar = BackwardArena(self.blocks, glogp.device, extra=self._misc_numel())
         if self.char:
             glogits = ops.logsoftmax_bwd(glogp, sv["logp"]).view(b, 1, gh.Wb, gh.Cout)
-            grads["text_generator.conv2.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)
-            grads["text_generator.conv2.bias"] = ops.colsum(glogits)
+            grads["text_generator.conv2.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh, out=ar.take_misc((gh.taps, gh.Cin, gh.Cout)))
+            grads["text_generator.conv2.bias"] = ops.colsum(glogits, out=ar.take_misc((glogits.shape[-1],)))
             dht = ops.conv_dgrad(glogits, self.head.weight, gh)
         else:
             glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
@@ -567,9 +587,9 @@ class DecoderText(_HipNet):
             grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()
             grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)[:self.vocab]
             dht = ops.conv_dgrad(glogits, w_pad, gh)
-        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w)
-        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, sv["gl"])
-        grads["feature_generator.bias"] = ops.colsum(g0)
+        g0, arena = trunk_backward(self.blocks, sv["trunk"], dht, grads, self._w, ar)
+        grads["feature_generator.weight"] = ops.conv_wgrad(sv["z4"], g0, gl, out=ar.take_misc((gl.taps, gl.Cin, gl.Cout)))
+        grads["feature_generator.bias"] = ops.colsum(g0, out=ar.take_misc((g0.shape[-1],)))
         gz = ops.conv_dgrad(g0, self._w(self.feature_generator), sv["gl"], out_dtype=torch.float32).view(b, -1) \
             if in_needs_grad[0] else None
         return [gz], grads, arena

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -570,7 +570,8 @@ def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
             assert bn_in is None
             vec, scal = (dy, x) if g.Cin == 1 else (x, dy)
             assert _is16(vec) and scal.dtype == torch.float32
-            _check(lib().mopoe_edge_wgrad_bf16(_p(vec), _p(scal), _p(dwp), C.byref(gc), max(g.Cin, g.Cout), stream))
+            _check(lib().mopoe_edge_wgrad_bf16(_p(vec), _p(scal), _p(dwp), C.byref(gc), max(g.Cin, g.Cout),
+                                               C.c_int32(int(out is not None)), stream))
             return dwp
         if not (_is16(x) and _is16(dy)):
             raise MopoeHipError("bf16 conv_wgrad needs both operands in bf16")
@@ -661,11 +662,15 @@ def bn_running_update(entries: Sequence, momentum=0.1):
     _check(lib().mopoe_bn_running_update(arr, len(entries), C.c_float(momentum), _stream()))
 
 
-def colsum(x):
-    _dev(x)
-    out = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device)
+def colsum(x, out=None):
+    """out: optional ZERO-FILLED [C] fp32 destination (a slice of a per-network gradient arena: no memset node)"""
+    _dev(x, out)
+    zero = out is not None
+    if out is None:
+        out = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.numel() == x.shape[-1]
     fn = lib().mopoe_colsum_bf16 if _is16(x) else lib().mopoe_colsum
-    _check(fn(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], _stream()))
+    _check(fn(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], C.c_int32(int(zero)), _stream()))
     return out
 
 
@@ -713,7 +718,7 @@ def latent_fwd(mu_in, lv_in, eps, row_start, w, norm):
 def latent_bwd(mu_in, lv_in, eps, row_start, w, norm, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd):
     """-> (d_mu_in[3], d_lv_in[3]) with None for absent modalities."""
     present = [t for t in mu_in if t is not None]
-    _dev(*present, eps, g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd)
+    _dev(*present, eps, *[t for t in (g_mus, g_lvs, g_jm, g_jl, g_z, g_klds, g_jd) if t is not None])
     b, d = present[0].shape
     dmu = [None if t is None else torch.empty_like(t) for t in mu_in]
     dlv = [None if t is None else torch.empty_like(t) for t in lv_in]

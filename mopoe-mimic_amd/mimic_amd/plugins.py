@@ -79,9 +79,13 @@ class FusedLaplace:
     def log_prob(self, value):  # elementwise; evaluation-only path (torch on device)
         return -math.log(2 * self.scale_value) - torch.abs(value - self.loc) / self.scale_value
 
+    def summed_nll(self, target, norm_value):
+        """-sum(log_prob(target)) / norm_value as one HIP reduction (0-dim tensor): what the loss adds up"""
+        return _LaplaceNll.apply(self.loc, target, self.scale_value, float(norm_value)).view(())
+
     def summed_log_prob(self, target, norm_value):
-        """sum(log_prob(target)) / norm_value as one HIP reduction (0-dim tensor)."""
-        return -_LaplaceNll.apply(self.loc, target, self.scale_value, float(norm_value)).view(())
+        """sum(log_prob(target)) / norm_value (0-dim tensor)."""
+        return -self.summed_nll(target, norm_value)
 
     def log_prob_rows(self, target):
         """log_prob summed per row of loc [R, ...] against target [B, ...] repeated R/B times (row r <-> r % B):
@@ -109,14 +113,17 @@ class FusedOneHotCategorical:
     def log_prob(self, value):  # value: one-hot [B,L,V]; evaluation-only path
         return (value * self.logits).sum(-1)
 
-    def summed_log_prob(self, target_ids, norm_value):
+    def summed_nll(self, target_ids, norm_value):
         """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised).  The text decoder hands over a
         [..., :V] view of a contiguous tensor padded along V (pad log-probabilities = -1e30): the reductions index the
         padded tensor directly, so neither a compaction copy nor a slice-gradient pass exists."""
         if target_ids.dim() == self.logits.dim():   # char encoding: the [B, L, num_features] one-hot tensor itself
-            return -_DenseNll.apply(self.logits, target_ids, float(norm_value)).view(())
+            return _DenseNll.apply(self.logits, target_ids, float(norm_value)).view(())
         lp = getattr(self.logits, "_mopoe_padded", self.logits)
-        return -_TokenNll.apply(lp, target_ids, float(norm_value)).view(())
+        return _TokenNll.apply(lp, target_ids, float(norm_value)).view(())
+
+    def summed_log_prob(self, target_ids, norm_value):
+        return -self.summed_nll(target_ids, norm_value)
 
     def log_prob_rows(self, target_ids):
         """per-row sum over the sequence of the picked log-probabilities: logits [R,L,V] against float ids [B,L]
@@ -154,6 +161,12 @@ class Modality(ABC):
         if hasattr(out_dist, "summed_log_prob"):
             return out_dist.summed_log_prob(target, norm_value)
         return out_dist.log_prob(target).sum() / norm_value
+
+    def calc_nll(self, out_dist, target: torch.Tensor, norm_value: int):
+        """-calc_log_prob without the two negations (losses.calc_log_probs negates what calc_log_prob returns)"""
+        if hasattr(out_dist, "summed_nll"):
+            return out_dist.summed_nll(target, norm_value)
+        return -self.calc_log_prob(out_dist, target, norm_value)
 
 
 class ModalityIMG(Modality):
@@ -224,3 +237,8 @@ class MimicText(Modality):
             return out_dist.summed_log_prob(target, norm_value)  # float ids, as the data loader yields them
         onehot = torch.nn.functional.one_hot(target.to(torch.int64), num_classes=self.args.vocab_size)
         return out_dist.log_prob(onehot).sum() / norm_value
+
+    def calc_nll(self, out_dist, target: torch.Tensor, norm_value: int):
+        fused = hasattr(out_dist, "summed_nll") and (self.args.text_encoding == "char"
+                                                     or target.dim() == out_dist.logits.dim() - 1)
+        return out_dist.summed_nll(target, norm_value) if fused else -self.calc_log_prob(out_dist, target, norm_value)

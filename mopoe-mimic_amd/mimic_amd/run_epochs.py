@@ -90,11 +90,14 @@ class ScalarPack:
         for k, v in routine["log_probs"].items():
             names.append("log_probs/" + k)
             vals.append(v.detach().reshape(1))
+        lat = []
         for k, (mu, lv) in res["latents"]["modalities"].items():
             if mu is None:
                 continue
             names += [f"latents/{k}/mu", f"latents/{k}/logvar"]
-            vals += [mu.detach().mean().reshape(1), lv.detach().mean().reshape(1)]
+            lat += [mu.detach(), lv.detach()]
+        if lat:   # (one stacked reduction instead of one mean per tensor)
+            vals.append(torch.stack(lat).mean(dim=(1, 2)))
         packed = torch.cat(vals)
         self.names = names
         if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():

@@ -209,36 +209,54 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
     return x, saved, running
 
 
-def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor], wsel=_master_weight):
+class BackwardArena:
+    """ONE zero-filled allocation per network backward: the fp64 reduction buffers, the small fp32 reduction buffers, the
+    weight gradients of every conv in the trunk (their split reductions accumulate with atomics into zeroed memory) and
+    `extra` floats for the network's gradients outside the trunk (stem / head / compressor weights and biases: their
+    kernels then need no memset of their own).  One fill node per network backward instead of ~8 per block + one per
+    bias; every gradient is a view into it, so data parallelism all-reduces a network with one collective."""
+
+    def __init__(self, blocks: List["BlockSpec"], device, extra: int = 0):
+        nd = sum(2 * b.g2.Cout + 4 * b.g1.Cin for b in blocks)
+        nf = sum(4 * b.g2.Cout + 6 * b.g1.Cin for b in blocks)
+        nw = sum(b.g1.taps * b.g1.Cin * b.g1.Cout + 2 * b.g2.taps * b.g2.Cin * b.g2.Cout for b in blocks)
+        extra = (extra + 3) // 4 * 4 + 64 + 48 * len(blocks)    # (pieces are 16-byte aligned: room for the padding)
+        raw = torch.zeros(nd * 8 + (nf + nw + extra) * 4, dtype=torch.uint8, device=device)
+        self.dbuf = raw[:nd * 8].view(torch.float64)
+        self.fbuf = raw[nd * 8:].view(torch.float32)
+        self.off = [0, 0]
+
+    def take_w(self, geom):
+        return self.take_misc((geom.taps, geom.Cin, geom.Cout))
+
+    def take_d(self, c):
+        v = self.dbuf[self.off[0]:self.off[0] + 2 * c].view(2, c)
+        self.off[0] += 2 * c
+        return v
+
+    def take_f(self, k, c):
+        return self.take_misc((k, c))
+
+    def take_misc(self, shape):
+        """a zero-filled fp32 tensor of `shape` (16-byte aligned)"""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        start = (self.off[1] + 3) // 4 * 4
+        if start + n > self.fbuf.numel():      # (a caller that asks for more than it announced: plain allocation)
+            return torch.zeros(tuple(shape), dtype=torch.float32, device=self.fbuf.device)
+        self.off[1] = start + n
+        return self.fbuf[start:start + n].view(tuple(shape))
+
+
+def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Tensor], wsel=_master_weight,
+                   arena: Optional[BackwardArena] = None):
     """g: gradient w.r.t. the trunk output.  Fills ``grads`` (keyed by parameter name relative to the
     network) and returns (gradient w.r.t. the trunk input, gradient arena).  Every gradient of the trunk's
     parameters is a view into the arena, so data parallelism can all-reduce a whole network with one
     collective and no staging copies (mimic_amd.parallel)."""
-    # one zero-filled arena for every small reduction buffer of this backward (instead of ~8 fills per block)
-    nd = sum(2 * b.g2.Cout + 4 * b.g1.Cin for b in blocks)
-    nf = sum(4 * b.g2.Cout + 6 * b.g1.Cin for b in blocks)
-    # ... and one for the weight gradients of every conv in the trunk (their split reductions accumulate with
-    # atomics into zeroed memory: one fill instead of one memset per layer)
-    nw = sum(b.g1.taps * b.g1.Cin * b.g1.Cout + 2 * b.g2.taps * b.g2.Cin * b.g2.Cout for b in blocks)
-    dbuf = torch.zeros(nd, dtype=torch.float64, device=g.device)
-    fbuf = torch.zeros(nf + nw, dtype=torch.float32, device=g.device)
-    off = [0, 0]
-
-    def take_w(geom):
-        n = geom.taps * geom.Cin * geom.Cout
-        v = fbuf[off[1]:off[1] + n].view(geom.taps, geom.Cin, geom.Cout)
-        off[1] += n
-        return v
-
-    def take_d(c):
-        v = dbuf[off[0]:off[0] + 2 * c].view(2, c)
-        off[0] += 2 * c
-        return v
-
-    def take_f(k, c):
-        v = fbuf[off[1]:off[1] + k * c].view(k, c)
-        off[1] += k * c
-        return v
+    ar = arena if arena is not None else BackwardArena(blocks, g.device)
+    take_w, take_d, take_f, fbuf = ar.take_w, ar.take_d, ar.take_f, ar.fbuf
 
     lane = _WgradLane(g.device, 0)
     lane_s = _WgradLane(g.device, 1)

@@ -268,8 +268,12 @@ def bn_running_update(entries, momentum=0.1):
         rv.mul_(1 - momentum).add_(momentum * unbiased.float())
 
 
-def colsum(x):
-    return _f(x).reshape(-1, x.shape[-1]).sum(0)
+def colsum(x, out=None):
+    r = _f(x).reshape(-1, x.shape[-1]).sum(0)
+    if out is not None:      # (a zero-filled slice of the gradient arena)
+        out.copy_(r)
+        return out
+    return r
 
 
 # ---- latent space -------------------------------------------------------------------------------
