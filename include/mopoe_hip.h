@@ -265,6 +265,11 @@ int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, 
                              int64_t target_rows, float* out, void* stream);
 /* text_encoding='char' (MimicText.py:37-40 skips the one-hot step; utils/likelihood.py:103-104): the target IS a dense
  * [B, L, num_features] tensor: out[r] = sum_i target[(r % target_rows) per_row + i] * logp[r per_row + i] */
+/* Gradient of the LOGITS for the token NLL in one pass (DataGeneratorText.py:64-77 LogSoftmax + MimicText.py:37-40 +
+ * Modality.py:25-30 backward): dx[r, v] = g[0] / norm * (exp(logp[r, v]) - [v == ids[r]]); dx fp32 or bf16 (dx_is_bf16).
+ * Replaces mopoe_token_nll_bwd (a memset + scatter of a [rows, V] tensor) followed by mopoe_logsoftmax_bwd. */
+int mopoe_token_softmax_grad(const float* logp, const float* ids, const float* g, int64_t rows, int32_t V, float norm,
+                             void* dx, int32_t dx_is_bf16, void* stream);
 int mopoe_dense_logprob_rows(const float* logp, const float* target, int64_t rows, int64_t per_row,
                              int64_t target_rows, float* out, void* stream);
 

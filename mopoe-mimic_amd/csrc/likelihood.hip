@@ -159,6 +159,25 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* dy, co
   }
 }
 
+// ---- gradient of the logits for the token NLL, in one pass ---------------------------------------------------------------
+// loss = -sum_r logp[r, id_r] / norm with upstream gradient g:  dlogits[r, v] = (g / norm) * (exp(logp[r, v]) - [v == id_r])
+// (= log-softmax backward of the one-hot gradient -g / norm, without ever writing that [rows, V] tensor or its memset)
+template <int NPT, typename TO>
+__global__ __launch_bounds__(256) void token_softmax_grad_kernel(const float* logp, const float* ids, const float* g, int V,
+                                                               float inv_norm, TO* dx) {
+  const long row = blockIdx.x;
+  const float c = g[0] * inv_norm;
+  int t = (int)ids[row];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  const float* yr = logp + row * V;
+  TO* xr = dx + row * V;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int col = threadIdx.x + k * 256;
+    if (col < V) xr[col] = to_store<TO>(c * (expf(yr[col]) - (col == t ? 1.f : 0.f)));
+  }
+}
+
 // ---- token NLL -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void token_nll_fwd_kernel(const float* logp, const float* ids, long rows, int V,
                                                           float inv_norm, float* out, double* ws, int nblocks) {
@@ -332,6 +351,26 @@ extern "C" int mopoe_logsoftmax_bwd_bf16out(const float* dy, const float* y, uin
   else if (V <= 256 * 16) hipLaunchKernelGGL((logsoftmax_bwd_kernel<16, bf16_t>), grid, blk, 0, st, dy, y, dx, V);
   else hipLaunchKernelGGL((logsoftmax_bwd_kernel<32, bf16_t>), grid, blk, 0, st, dy, y, dx, V);
   return check_launch("logsoftmax_bwd_bf16out");
+}
+
+extern "C" int mopoe_token_softmax_grad(const float* logp, const float* ids, const float* g, int64_t rows, int32_t V, float norm,
+                                        void* dx, int32_t dx_is_bf16, void* stream) {
+  if (!logp || !ids || !g || !dx || rows <= 0 || V <= 0 || V > 256 * 32 || norm <= 0.f || rows > 0x7fffffffL) {
+    set_error("token_softmax_grad: bad arguments (V <= 8192)"); return MOPOE_ERR_ARG;
+  }
+  const dim3 grid((unsigned)rows), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float inv = 1.0f / norm;
+#define MOPOE_TSG(NPT_)                                                                                                          \
+  do {                                                                                                                           \
+    if (dx_is_bf16) hipLaunchKernelGGL((token_softmax_grad_kernel<NPT_, bf16_t>), grid, blk, 0, st, logp, ids, g, V, inv, (bf16_t*)dx); \
+    else hipLaunchKernelGGL((token_softmax_grad_kernel<NPT_, float>), grid, blk, 0, st, logp, ids, g, V, inv, (float*)dx);          \
+  } while (0)
+  if (V <= 256 * 4) MOPOE_TSG(4);
+  else if (V <= 256 * 16) MOPOE_TSG(16);
+  else MOPOE_TSG(32);
+#undef MOPOE_TSG
+  return check_launch("token_softmax_grad");
 }
 
 extern "C" int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm, float* out,

@@ -42,7 +42,8 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         net = ctx.net
-        gouts = [None if g is None else g.contiguous() for g in gouts]
+        from .plugins import is_zero_placeholder   # (a stride-0 zero gradient stays as it is: plugins.HeadCtx)
+        gouts = [None if g is None else (g if is_zero_placeholder(g) else g.contiguous()) for g in gouts]
         gin, grads, arena = net._run_backward(ctx.saved, ctx.in_needs_grad, *gouts)
         ctx.saved = None
         plist = [grads.get(name) for name, _ in net._named_param_list()]
@@ -542,6 +543,9 @@ class DecoderText(_HipNet):
 
     def forward(self, z_style, z_content):
         (logp_pad,) = self._call(z_content)
+        hc = getattr(self, "_head_ctx_latest", None)
+        if hc is not None and logp_pad.requires_grad:
+            logp_pad._mopoe_head_ctx = hc
         if self.vpad == self.vocab:
             return [logp_pad]
         logp = logp_pad[..., :self.vocab]          # what the reference returns: [B, L, V] log-probabilities
@@ -566,9 +570,14 @@ class DecoderText(_HipNet):
             w_pad, b_pad = self._padded_head()
             logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
             logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
+        hc = None
+        if not self.char:         # (grad mode is off inside an autograd Function's forward: forward() decides whether to expose it)
+            from .plugins import HeadCtx
+            hc = HeadCtx()        # the token likelihood hands its gradient over in compact form (plugins.HeadCtx)
+        object.__setattr__(self, "_head_ctx_latest", hc)
         if self.training:
             apply_running_updates(running)
-        return (logp,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logp=logp, arena=arena)
+        return (logp,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logp=logp, arena=arena, head_ctx=hc)
 
     def _run_backward(self, sv, in_needs_grad, glogp):
         grads: Dict[str, torch.Tensor] = {}
@@ -581,7 +590,19 @@ class DecoderText(_HipNet):
             grads["text_generator.conv2.bias"] = ops.colsum(glogits, out=ar.take_misc((glogits.shape[-1],)))
             dht = ops.conv_dgrad(glogits, self.head.weight, gh)
         else:
-            glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
+            from .plugins import is_zero_placeholder
+            hc = sv.get("head_ctx")
+            pend = hc.pending if hc is not None else None
+            if hc is not None:
+                hc.pending = None
+            if pend is not None:      # token NLL: the logits' gradient in one pass, no [B, L, V] one-hot gradient
+                ids, g, norm = pend
+                glogits = ops.token_softmax_grad(sv["logp"], ids, g, norm, out_dtype=self.act_dtype)
+                if not is_zero_placeholder(glogp):    # (the log-probabilities had other consumers as well)
+                    glogits = glogits + ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype)
+                glogits = glogits.view(b, 1, gh.Ws, gh.Cout)
+            else:
+                glogits = ops.logsoftmax_bwd(glogp, sv["logp"], out_dtype=self.act_dtype).view(b, 1, gh.Ws, gh.Cout)
             k = len(self.blocks)
             w_pad = self._head_pad[0]
             grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()

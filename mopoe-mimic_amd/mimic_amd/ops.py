@@ -769,6 +769,16 @@ def logsoftmax_bwd(dy, y, inplace=False, out_dtype=None):
     return dx
 
 
+def token_softmax_grad(logp, ids, g, norm, out_dtype=None):
+    """gradient of the logits for loss = -sum_r logp[r, ids[r]] / norm with upstream gradient g (1 element), one pass"""
+    _dev(logp, ids, g)
+    out_dtype = out_dtype or torch.float32
+    dx = torch.empty(logp.shape, dtype=out_dtype, device=logp.device)
+    _check(lib().mopoe_token_softmax_grad(_p(logp), _p(ids), _p(g), C.c_int64(ids.numel()), logp.shape[-1], C.c_float(norm),
+                                          _p(dx), C.c_int32(int(out_dtype == BF16)), _stream()))
+    return dx
+
+
 def token_nll_fwd(logp, ids, norm):
     _dev(logp, ids)
     out = torch.empty(1, dtype=torch.float32, device=logp.device)

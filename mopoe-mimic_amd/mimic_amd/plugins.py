@@ -33,17 +33,50 @@ class _LaplaceNll(torch.autograd.Function):
         return ops.laplace_nll_bwd(loc, tgt, g.contiguous(), ctx.scale, ctx.norm), None, None, None
 
 
+class HeadCtx:
+    """Side channel between the text decoder and the token likelihood.  The gradient of the token NLL with respect to the
+    log-probabilities is one non-zero per row; written out it is a [B, L, V] tensor (115 MB at C2, 460 MB at C3) plus its
+    memset, only to be read back by the log-softmax backward.  When the decoder has left a HeadCtx on its output, the
+    likelihood's backward hands over (ids, upstream gradient, norm) here and returns a stride-0 ZERO tensor as the dense
+    gradient; the decoder's backward then makes the logits' gradient in one pass (ops.token_softmax_grad) and adds
+    whatever dense gradient other consumers of the log-probabilities may have produced."""
+
+    def __init__(self):
+        self.pending = None    # (ids, g, norm) of the backward in flight
+
+
+_zero_scalars = {}
+
+
+def zero_placeholder(shape, device):
+    """a zero tensor of `shape` that occupies 4 bytes (stride 0); is_zero_placeholder() recognises it"""
+    key = (device.type, device.index)
+    z = _zero_scalars.get(key)
+    if z is None:
+        z = _zero_scalars[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z.expand(shape)
+
+
+def is_zero_placeholder(t) -> bool:
+    z = _zero_scalars.get((t.device.type, t.device.index))
+    return z is not None and t.data_ptr() == z.data_ptr() and all(s == 0 for s in t.stride())
+
+
 class _TokenNll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, ids, norm):
         ids_c = ids.contiguous()
         ctx.save_for_backward(ids_c)
         ctx.shape, ctx.norm = tuple(logp.shape), norm
+        ctx.head = getattr(logp, "_mopoe_head_ctx", None)
         return ops.token_nll_fwd(logp.contiguous(), ids_c, norm)
 
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
+        if ctx.head is not None and ctx.head.pending is None:
+            ctx.head.pending = (ids, g.contiguous(), ctx.norm)
+            return zero_placeholder(ctx.shape, g.device), None, None
         return ops.token_nll_bwd(ids, g.contiguous(), ctx.shape, ctx.norm), None, None
 
 

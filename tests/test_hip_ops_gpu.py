@@ -386,6 +386,25 @@ def test_dense_nll_and_rows(b, L, F, onehot):
           rtol=2e-6, atol_rel=2e-6)
 
 
+@pytest.mark.parametrize("b,L,V", [(4, 128, 3520), (3, 7, 52), (2, 5, 9), (1, 3, 5000)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_token_softmax_grad(b, L, V, out_dtype):
+    """mopoe_token_softmax_grad == token_nll_bwd followed by logsoftmax_bwd (what it replaces), and the emulation"""
+    gen = torch.Generator().manual_seed(b * L + V)
+    logp = torch.log_softmax(torch.randn(b, L, V, generator=gen), dim=-1)
+    ids = torch.randint(0, V, (b, L), generator=gen).float()
+    g = torch.tensor([0.73])
+    ref = TB.token_softmax_grad(logp.double(), ids, g.double(), float(b)).float()
+    got = ops.token_softmax_grad(logp.to(DEV), ids.to(DEV), g.to(DEV), float(b), out_dtype=out_dtype)
+    assert got.dtype == out_dtype
+    two_step = ops.logsoftmax_bwd(ops.token_nll_bwd(ids.to(DEV), g.to(DEV), (b, L, V), float(b)), logp.to(DEV))
+    if out_dtype == torch.float32:
+        check("token_softmax_grad", got, ref, rtol=2e-6, atol_rel=2e-6)
+        check("token_softmax_grad/vs_two_kernels", got, two_step, rtol=2e-6, atol_rel=2e-6)
+    else:
+        check("token_softmax_grad/bf16", got.float(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol_rel=1e-4)
+
+
 @pytest.mark.parametrize("rows,tb,L,V", [(12, 4, 128, 50), (6, 3, 300, 3517), (5, 5, 1, 9)])
 def test_token_logprob_rows(rows, tb, L, V):
     gen = torch.Generator().manual_seed(rows + V)

@@ -307,3 +307,51 @@ def check_char_against_g5(exp, g, mode, batch, device, rtol=1e-4, atol=1e-5, gra
         if name.endswith(".bias") and (pre + name[:-4] + "weight") in g.files:
             scale = max(scale, np.abs(g[pre + name[:-4] + "weight"]).max())
         np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=grad_rtol, atol=grad_atol * scale, err_msg=name)
+
+
+def test_token_likelihood_gradient_side_channel(monkeypatch):
+    """plugins.HeadCtx: the token NLL hands its gradient to the text decoder in compact form (ops.token_softmax_grad: no
+    [B, L, V] one-hot gradient, no log-softmax backward); a second consumer of the log-probabilities takes the dense path
+    and both parts are added.  Both forms against plain autograd on the same log-probabilities."""
+    from mimic_amd import ops
+    torch_backend.install(monkeypatch)
+    g = load("g0_s64")
+    cfg = cfg_from(g["cfg"])
+    calls = {"fused": 0, "dense_bwd": 0, "lsm_bwd": 0}
+    for name, key in (("token_softmax_grad", "fused"), ("token_nll_bwd", "dense_bwd"), ("logsoftmax_bwd", "lsm_bwd")):
+        orig = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda o, k: (lambda *a, **kw: (calls.__setitem__(k, calls[k] + 1), o(*a, **kw))[1]))(orig, key))
+    grads = {}
+    for extra in (False, True):
+        exp = build_exp(cfg, g0_state(g), "cpu", "train_nodrop", eps=torch.from_numpy(g["train_nodrop/eps"]))
+        dec = exp.mm_vae.decoder_text
+        z = torch.from_numpy(g["train_nodrop/joint/mu"]).clone().requires_grad_(True)
+        (logp,) = dec(None, z)
+        ids = g0_batch(g)["text"]
+        dist = exp.modalities["text"].likelihood(logits=logp)
+        loss = exp.modalities["text"].calc_nll(dist, ids, 4)
+        if extra:
+            loss = loss + 0.05 * (logp * torch.linspace(0, 1, logp.shape[-1])).sum()
+        before = dict(calls)
+        loss.backward()
+        used = {k: calls[k] - before[k] for k in calls}
+        assert used == ({"fused": 1, "dense_bwd": 0, "lsm_bwd": 1} if extra else {"fused": 1, "dense_bwd": 0, "lsm_bwd": 0}), used
+        grads[extra] = (z.grad.clone(), {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None})
+        # plain autograd reference: the decoder's log-probabilities as a leaf, dense one-hot likelihood
+        lp = logp.detach().clone().requires_grad_(True)
+        ref = -(torch.nn.functional.one_hot(ids.long(), lp.shape[-1]) * lp).sum() / 4
+        if extra:
+            ref = ref + 0.05 * (lp * torch.linspace(0, 1, lp.shape[-1])).sum()
+        ref.backward()
+        exp2 = build_exp(cfg, g0_state(g), "cpu", "train_nodrop", eps=torch.from_numpy(g["train_nodrop/eps"]))
+        z2 = torch.from_numpy(g["train_nodrop/joint/mu"]).clone().requires_grad_(True)
+        monkeypatch.setattr(type(exp2.mm_vae.decoder_text), "_head_ctx_off", True, raising=False)
+        (logp2,) = exp2.mm_vae.decoder_text(None, z2)
+        logp2._mopoe_head_ctx = None
+        getattr(logp2, "_mopoe_padded", logp2)._mopoe_head_ctx = None      # dense path: gradient of the leaf pushed in
+        logp2.backward(lp.grad)
+        torch.testing.assert_close(z.grad, z2.grad, rtol=1e-4, atol=1e-5 * z2.grad.abs().max().item())
+        for n, p in exp2.mm_vae.decoder_text.named_parameters():
+            if p.grad is not None:
+                err = (grads[extra][1][n] - p.grad).abs().max().item()
+                assert err <= 1e-4 * max(p.grad.abs().max().item(), 1e-1), (n, err, p.grad.abs().max().item())   # (analytically-zero biases hold 1e-7 noise)

@@ -19,7 +19,7 @@ OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_red
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
-            "dense_logprob_rows", "conv_mix_supported"]
+            "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad"]
 
 
 def install(monkeypatch):
@@ -380,6 +380,13 @@ def token_logprob_rows(logp, ids):
     rows, tb = logp.shape[0], ids.shape[0]
     idx = ids.long().repeat(rows // tb, 1)
     return logp.gather(-1, idx.unsqueeze(-1)).squeeze(-1).sum(dim=1)
+
+
+def token_softmax_grad(logp, ids, g, norm, out_dtype=None):
+    c = _f(g).reshape(()) / norm
+    onehot = torch.zeros_like(logp).scatter_(-1, ids.long().clamp(0, logp.shape[-1] - 1).unsqueeze(-1), 1.0)
+    dx = c * (torch.exp(logp) - onehot)
+    return dx.to(out_dtype) if out_dtype is not None else dx
 
 
 def dense_logprob_rows(logp, target):
