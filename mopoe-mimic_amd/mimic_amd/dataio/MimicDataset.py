@@ -21,7 +21,6 @@ import os
 import pickle
 import random
 import re
-from collections import Counter, OrderedDict, defaultdict
 
 import numpy as np
 import torch
@@ -70,50 +69,95 @@ class Mimic_testing(Dataset):
         return int(getattr(self.flags, "testing_batches", 2)) * self.flags.batch_size
 
 
-class OrderedCounter(Counter, OrderedDict):
-    """Counter that remembers the order elements are first encountered (vocabulary order = first occurrence)."""
-
-    def __repr__(self):
-        return "%s(%r)" % (self.__class__.__name__, OrderedDict(self))
-
-    def __reduce__(self):
-        return self.__class__, (OrderedDict(self),)
+SPECIAL_TOKENS = ("<exc>", "<pad>", "<eos>")     # ids 0, 1, 2: out-of-vocabulary, padding, end of sentence
 
 
 def to_tensor(data):
     return torch.Tensor(data)
 
 
+def count_words(sentences):
+    """word -> occurrences over the lower-cased, tokenised sentences, in order of first occurrence"""
+    counts = {}
+    for line in sentences:
+        for w in word_tokenize(line.lower()):
+            counts[w] = counts.get(w, 0) + 1
+    return counts
+
+
+def build_vocabulary(counts, min_occ: int):
+    """the reference's rule (MimicDataset.py:341-380): the three special tokens first, then every word seen MORE than
+    min_occ times, numbered in order of first occurrence; returns (w2i, i2w, excluded words)"""
+    kept = list(SPECIAL_TOKENS) + [w for w, n in counts.items() if n > min_occ and w not in SPECIAL_TOKENS]
+    w2i = {w: i for i, w in enumerate(kept)}
+    i2w = {i: w for i, w in enumerate(kept)}
+    dropped = [w for w, n in counts.items() if not (n > min_occ and w not in SPECIAL_TOKENS)]
+    return w2i, i2w, dropped
+
+
+def encode_sentence(line: str, w2i, length: int):
+    """tokens cut to length - 1, '<eos>', '<pad>' up to length; ids with '<exc>' for words outside the vocabulary"""
+    tok = word_tokenize(line.lower())[:length - 1] + ["<eos>"]
+    n_real = len(tok)
+    tok += ["<pad>"] * (length - n_real)
+    exc = w2i["<exc>"]
+    return {"tok": tok, "idx": [w2i.get(w, exc) for w in tok], "length": n_real}
+
+
+def _write_json(path, obj):
+    with io.open(path, "wb") as f:
+        f.write(json.dumps(obj, ensure_ascii=False).encode("utf8", "replace"))
+
+
 class MimicSentences(Dataset):
-    """Word encoding of the report findings (reference MimicDataset.py:224-396)."""
+    """Word encoding of the report findings with the reference's cache files (MimicDataset.py:224-396): directory
+    `oc:<min_occ>_msl:<len>/` holding `mimic.vocab` ({"w2i", "i2w"} as JSON), `mimic.<split>.s<len>` ({"<row>": {"tok", "idx",
+    "length"}} as JSON), `mimic.unique` / `mimic.all` (pickles of the excluded words / the word counts).  The vocabulary is
+    built from the training split only; the other splits need it to exist."""
 
     def __init__(self, max_squence_len: int, data_dir: str, findings, split: str, transform=False, min_occ: int = 3):
         super().__init__()
-        self.split, self.data_dir = split, data_dir
+        self.split, self.data_dir, self.findings = split, data_dir, findings
         self.max_sequence_length, self.min_occ = max_squence_len, min_occ
         self.transform = to_tensor if transform else None
-        self.findings = findings
-        self.gen_dir = os.path.join(self.data_dir, "oc:{}_msl:{}".format(self.min_occ, self.max_sequence_length))
+        self.gen_dir = os.path.join(data_dir, f"oc:{min_occ}_msl:{max_squence_len}")
         self.raw_data_path = os.path.join(data_dir, split + "_findings.csv")
+        self.data_file, self.vocab_file = f"mimic.{split}.s{max_squence_len}", "mimic.vocab"
         os.makedirs(self.gen_dir, exist_ok=True)
-        self.data_file = "mimic.{}.s{}".format(split, self.max_sequence_length)
-        self.vocab_file = "mimic.vocab"
-        if not os.path.exists(os.path.join(self.gen_dir, self.data_file)):
-            self._create_data()
-        else:
-            self._load_data()
+        self._vocabulary()
+        data_path = os.path.join(self.gen_dir, self.data_file)
+        if not os.path.exists(data_path):
+            rows = {i: encode_sentence(line, self.w2i, max_squence_len) for i, line in enumerate(findings)}
+            _write_json(data_path, rows)
+        with open(data_path, "rb") as f:
+            self.data = json.load(f)
+
+    def _vocabulary(self):
+        path = os.path.join(self.gen_dir, self.vocab_file)
+        if not os.path.exists(path):
+            assert self.split == "train", "Vocabulary can only be created for training file."
+            counts = count_words(self.findings)
+            w2i, i2w, dropped = build_vocabulary(counts, self.min_occ)
+            _write_json(path, {"w2i": w2i, "i2w": i2w})
+            with open(os.path.join(self.gen_dir, "mimic.unique"), "wb") as f:
+                pickle.dump(np.array(dropped), f)
+            with open(os.path.join(self.gen_dir, "mimic.all"), "wb") as f:
+                pickle.dump(counts, f)
+        with open(path, "r") as f:
+            vocab = json.load(f)
+        self.w2i, self.i2w = vocab["w2i"], vocab["i2w"]
 
     def __len__(self):
         return len(self.data)
 
     def __getitem__(self, idx: int):
-        sent = self.data[str(idx)]["idx"]
-        return self.transform(sent) if self.transform is not None else sent
+        ids = self.data[str(idx)]["idx"]
+        return self.transform(ids) if self.transform is not None else ids
 
     vocab_size = property(lambda self: len(self.w2i))
     pad_idx = property(lambda self: self.w2i["<pad>"])
     eos_idx = property(lambda self: self.w2i["<eos>"])
-    unk_idx = property(lambda self: self.w2i["<unk>"])
+    unk_idx = property(lambda self: self.w2i["<exc>"])
 
     def get_w2i(self):
         return self.w2i
@@ -124,65 +168,6 @@ class MimicSentences(Dataset):
     def id_matrix(self) -> torch.Tensor:
         """every sentence as one int32 [N, len] tensor (what DeviceResidentMimic keeps in HBM)"""
         return torch.tensor([self.data[str(i)]["idx"] for i in range(len(self.data))], dtype=torch.int32)
-
-    def _load_data(self, vocab=True):
-        with open(os.path.join(self.gen_dir, self.data_file), "rb") as file:
-            self.data = json.load(file)
-        if vocab:
-            self._load_vocab()
-
-    def _load_vocab(self):
-        if not os.path.exists(os.path.join(self.gen_dir, self.vocab_file)):
-            self._create_vocab()
-        with open(os.path.join(self.gen_dir, self.vocab_file), "r") as vocab_file:
-            vocab = json.load(vocab_file)
-        self.w2i, self.i2w = vocab["w2i"], vocab["i2w"]
-
-    def _create_data(self):
-        if self.split == "train" and not os.path.exists(os.path.join(self.gen_dir, self.vocab_file)):
-            self._create_vocab()
-        else:
-            self._load_vocab()
-        data = defaultdict(dict)
-        for line in self._tokenize_raw_data():
-            tok = word_tokenize(line.lower())[:self.max_sequence_length - 1] + ["<eos>"]
-            length = len(tok)
-            tok.extend(["<pad>"] * (self.max_sequence_length - length))
-            i = len(data)
-            data[i]["tok"] = tok
-            data[i]["idx"] = [self.w2i.get(w, self.w2i["<exc>"]) for w in tok]
-            data[i]["length"] = length
-        with io.open(os.path.join(self.gen_dir, self.data_file), "wb") as data_file:
-            data_file.write(json.dumps(data, ensure_ascii=False).encode("utf8", "replace"))
-        self._load_data(vocab=False)
-
-    def _tokenize_raw_data(self):
-        return [sentence for sentence in self.findings]
-
-    def _create_vocab(self):
-        assert self.split == "train", "Vocabulary can only be created for training file."
-        occ_register = OrderedCounter()
-        w2i, i2w = {}, {}
-        special_tokens = ["<exc>", "<pad>", "<eos>"]
-        for st in special_tokens:
-            i2w[len(w2i)] = st
-            w2i[st] = len(w2i)
-        for line in self._tokenize_raw_data():
-            occ_register.update(word_tokenize(line.lower()))
-        unq_words = []
-        for w, occ in occ_register.items():
-            if occ > self.min_occ and w not in special_tokens:
-                i2w[len(w2i)] = w
-                w2i[w] = len(w2i)
-            else:
-                unq_words.append(w)
-        with io.open(os.path.join(self.gen_dir, self.vocab_file), "wb") as vocab_file:
-            vocab_file.write(json.dumps(dict(w2i=w2i, i2w=i2w), ensure_ascii=False).encode("utf8", "replace"))
-        with open(os.path.join(self.gen_dir, "mimic.unique"), "wb") as unq_file:
-            pickle.dump(np.array(unq_words), unq_file)
-        with open(os.path.join(self.gen_dir, "mimic.all"), "wb") as a_file:
-            pickle.dump(occ_register, a_file)
-        self._load_vocab()
 
 
 def one_hot_encode(len_seq: int, alphabet: str, seq: str) -> torch.Tensor:
