@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 10
+#define MOPOE_ABI_VERSION 11
 
 /* error codes */
 #define MOPOE_OK 0
@@ -341,6 +341,28 @@ int mopoe_embedding_fwd_bf16(const float* ids, const float* table, uint16_t* out
                              void* stream);
 int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtable, int64_t rows, int32_t V, int32_t D,
                              int32_t padding_idx, void* stream);
+
+/* ---- optimiser step ------------------------------------------------------------------------------------
+ * Replaces exp.optimizer.step() of the reference's train loop (mimic/run_epochs.py:131) for the optimiser
+ * mimic/utils/experiment.py:171-178 builds: optim.Adam(params, lr, betas), no weight decay, no amsgrad.  Arithmetic of
+ * PyTorch's fused capturable Adam: step += 1; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ * p -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).
+ * One record per parameter tensor (HOST array; the records travel in the kernel arguments, 64 per launch, so no device
+ * table has to be built or kept alive and a hipGraph capture bakes the pointers into its nodes).  g == NULL: the tensor
+ * and its state are left untouched (optim.Adam skips parameters whose .grad is None).  p16 (optional): the bf16 copy of
+ * the updated parameter is written in the same pass (the bf16 family's MFMA operands).
+ * step: device scalar (float), incremented first.  lr_dev: device scalar or NULL (then `lr`).  coef: float[2] device scratch.
+ * The hyper-parameters are doubles, as in optim.Adam: 1 - beta2 formed from the float 0.999 is off by 1.3e-5 relative. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  uint16_t* p16;
+  int64_t n;
+} mopoe_adam_seg;
+int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const float* lr_dev, double lr, double beta1,
+                    double beta2, double eps, float* coef, void* stream);
 
 /* ---- profiling support for bench.py ------------------------------------------------------------------
  * When enabled, every launch of the implicit-GEMM kernels is bracketed by HIP events on the launch

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -56,6 +56,11 @@ class _MixRef(C.Structure):   # mopoe_mix_ref
 class _RunDesc(C.Structure):
     _fields_ = [("sums", C.c_void_p), ("rmean", C.c_void_p), ("rvar", C.c_void_p), ("C", C.c_int32),
                 ("count", C.c_int32)]
+
+
+class _AdamSeg(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("p16", C.c_void_p),
+                ("n", C.c_int64)]
 
 
 @dataclass(frozen=True)
@@ -660,6 +665,29 @@ def bn_running_update(entries: Sequence, momentum=0.1):
         _dev(sums, rm, rv)
         arr[i] = _RunDesc(sums.data_ptr(), rm.data_ptr(), rv.data_ptr(), rm.numel(), count)
     _check(lib().mopoe_bn_running_update(arr, len(entries), C.c_float(momentum), _stream()))
+
+
+def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None):
+    """One Adam step over all tensors (header: mopoe_adam_step).  params / grads / ms / vs: equally long lists of fp32
+    tensors (a grad may be None: that tensor is skipped, like optim.Adam does); step: device scalar (float), incremented;
+    lr: float or device scalar; coef: float[2] device scratch; lowp: optional list of bf16 copies (or None entries)
+    rewritten in the same pass."""
+    n = len(params)
+    arr = (_AdamSeg * n)()
+    for i in range(n):
+        p_, g_ = params[i], grads[i]
+        if g_ is None:
+            arr[i] = _AdamSeg(p_.data_ptr(), None, ms[i].data_ptr(), vs[i].data_ptr(), None, p_.numel())
+            continue
+        if g_.dtype != torch.float32 or p_.dtype != torch.float32 or g_.numel() != p_.numel():
+            raise MopoeHipError("adam_step: parameters and gradients must be fp32 tensors of equal size")
+        _dev(p_, g_, ms[i], vs[i])
+        lp = lowp[i] if lowp is not None else None
+        arr[i] = _AdamSeg(p_.data_ptr(), g_.data_ptr(), ms[i].data_ptr(), vs[i].data_ptr(),
+                          None if lp is None else lp.data_ptr(), p_.numel())
+    lr_dev = lr if isinstance(lr, torch.Tensor) else None
+    _check(lib().mopoe_adam_step(arr, n, _p(step), _p(lr_dev), C.c_double(0.0 if lr_dev is not None else float(lr)),
+                                 C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _p(coef), _stream()))
 
 
 def colsum(x, out=None):

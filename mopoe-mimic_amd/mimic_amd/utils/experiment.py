@@ -4,6 +4,7 @@ classifiers, CSV bookkeeping, fonts and plotting are outside the training step (
 from __future__ import annotations
 
 import argparse
+import os
 from itertools import chain, combinations
 
 import torch
@@ -95,20 +96,24 @@ class HotPathExperiment:
 
     def set_optimizer(self, capturable=None):
         params = list(self.mm_vae.parameters())
-        # same Adam arithmetic as the reference's optim.Adam (experiment.py:171-178); the fused
-        # multi-tensor implementation updates all ~370 tensors in a handful of launches.
-        # capturable (default on the GPU): step counters AND the learning rate live on the device, so the step can sit
-        # inside a hipGraph (run_epochs.GraphedTrainStep) and a scheduler's lr change (Callbacks' ReduceLROnPlateau
-        # fills the tensor in place) reaches the captured optimiser without a re-capture
+        # same Adam arithmetic as the reference's optim.Adam (experiment.py:171-178).  On the GPU the step is
+        # mimic_amd.optim.HipAdam: every tensor updated by one kernel family (csrc/adam.hip), step counter AND learning
+        # rate on the device, so the step can sit inside a hipGraph (run_epochs.GraphedTrainStep) and a scheduler's lr
+        # change (Callbacks' ReduceLROnPlateau fills the tensor in place) reaches the captured optimiser without a
+        # re-capture.  MOPOE_TORCH_ADAM=1 (or capturable=False) keeps PyTorch's own fused multi-tensor Adam.
         fused = bool(params) and all(p.is_cuda for p in params)
         if capturable is None:
             capturable = fused
         capturable = bool(capturable and fused)
         lr = self.flags.initial_learning_rate
+        betas = (self.flags.beta_1, self.flags.beta_2)
+        if capturable and os.environ.get("MOPOE_TORCH_ADAM", "0") != "1":
+            from ..optim import HipAdam
+            self.optimizer = HipAdam([p for p in params if p.requires_grad], lr=lr, betas=betas)
+            return
         if capturable:
             lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
-        self.optimizer = optim.Adam(params, lr=lr, betas=(self.flags.beta_1, self.flags.beta_2), fused=fused,
-                                    capturable=capturable)
+        self.optimizer = optim.Adam(params, lr=lr, betas=betas, fused=fused, capturable=capturable)
 
     def set_rec_weights(self):
         f = self.flags

@@ -289,6 +289,59 @@ def test_bn_running_update():
         check("running_var", rv, rv_r, 1e-5, 1e-5)
 
 
+def test_adam_step_against_fused_adam():
+    """csrc/adam.hip against PyTorch's fused capturable Adam (the kernel it replaces) and the CPU restatement: many
+    tensors (> one launch's 64 records), sizes around the 4096-element chunk and the 4-element vector, a tensor without
+    gradient, a misaligned view, the bf16 copy, a learning-rate change on the device"""
+    gen = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 4, 5, 4095, 4096, 4097, 8192 + 2, 100_000, 1_638_400] + [17 + 13 * i for i in range(70)]
+    big = torch.randn(sum(sizes) + 8, generator=gen)
+    host, off = [], 0
+    for i, n in enumerate(sizes):
+        o = off + (1 if i == 7 else 0)                 # tensor 7 starts 4 bytes off a 16-byte boundary
+        host.append(big[o:o + n].clone())
+        off += n
+    p_hip = [h.to(DEV) for h in host]
+    stash = torch.zeros(sizes[7] + 4, device=DEV)
+    stash[1:1 + sizes[7]] = p_hip[7]
+    p_hip[7] = stash[1:1 + sizes[7]]
+    assert p_hip[7].data_ptr() % 16 == 4
+    p_ref = [torch.nn.Parameter(h.to(DEV)) for h in host]
+    p_cpu = [h.clone() for h in host]
+    m, v = [torch.zeros_like(p) for p in p_hip], [torch.zeros_like(p) for p in p_hip]
+    m_c, v_c = [torch.zeros_like(p) for p in p_cpu], [torch.zeros_like(p) for p in p_cpu]
+    lowp = [torch.zeros(p.numel(), dtype=torch.bfloat16, device=DEV) if i in (5, 9, 12) else None for i, p in enumerate(p_hip)]
+    lr = torch.tensor(2e-3, device=DEV)
+    lr_ref = torch.tensor(2e-3, device=DEV)
+    step, coef = torch.zeros((), device=DEV), torch.zeros(2, device=DEV)
+    step_c = torch.zeros(())
+    opt = torch.optim.Adam(p_ref, lr=lr_ref, betas=(0.9, 0.999), fused=True, capturable=True)
+    for it in range(4):
+        grads = [torch.randn(n, generator=gen) * (0.01 if i % 3 else 3.0) for i, n in enumerate(sizes)]
+        grads[2] = None
+        for p, g in zip(p_ref, grads):
+            p.grad = None if g is None else g.to(DEV)
+        opt.step()
+        ops.adam_step(p_hip, [None if g is None else g.to(DEV) for g in grads], m, v, step, lr, 0.9, 0.999, 1e-8, coef, lowp=lowp)
+        TB.adam_step(p_cpu, grads, m_c, v_c, step_c, 2e-3 if it < 2 else 5e-4, 0.9, 0.999, 1e-8, None)
+        if it == 1:
+            lr.fill_(5e-4)
+            lr_ref.fill_(5e-4)
+    torch.cuda.synchronize()
+    assert float(step) == 4
+    for i, (a, b, c) in enumerate(zip(p_hip, p_ref, p_cpu)):
+        check(f"adam[{i}] vs fused", a, b.detach().cpu(), 2e-6, 2e-7)
+        check(f"adam[{i}] vs restatement", a, c, 2e-6, 2e-7)
+        if lowp[i] is not None:
+            assert torch.equal(lowp[i].cpu(), a.cpu().to(torch.bfloat16)), i
+    assert torch.equal(p_hip[2].cpu(), host[2]) and float(m[2].abs().sum()) == 0.0
+    check("exp_avg", m[9], opt.state[p_ref[9]]["exp_avg"].cpu(), 2e-6, 1e-6)
+    # (PyTorch's GPU kernel forms 1 - beta2 in float: 0.00100005; the reference's CPU Adam and this kernel use the double)
+    check("exp_avg_sq", v[9], opt.state[p_ref[9]]["exp_avg_sq"].cpu(), 1e-4, 1e-6)
+    check("exp_avg vs restatement", m[9], m_c[9], 2e-6, 2e-7)
+    check("exp_avg_sq vs restatement", v[9], v_c[9], 2e-6, 2e-7)
+
+
 @pytest.mark.parametrize("present", [(1, 1, 1), (1, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0)])
 @pytest.mark.parametrize("b,d", [(64, 128), (7, 8), (65, 64)])
 def test_latent(present, b, d):

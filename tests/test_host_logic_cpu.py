@@ -153,6 +153,50 @@ def test_g3_adam_trajectory_host(monkeypatch):
           1e-4, 1e-6)
 
 
+def test_hip_adam_host_logic(monkeypatch):
+    """mimic_amd.optim.HipAdam (flat moments, one shared step counter, records per tensor) against torch.optim.Adam:
+    gradients that are None, a learning-rate change through param_groups (what ReduceLROnPlateau does), state_dict round trip"""
+    from mimic_amd.optim import HipAdam
+    torch_backend.install(monkeypatch)
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(7,), (3, 5, 4), (1,), (130, 9), (2, 2)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=gen)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt = HipAdam(mine, lr=3e-3, betas=(0.9, 0.999))
+    opt_ref = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.999))
+    assert opt.defaults["capturable"] and len(opt.state) == len(shapes)
+
+    def run(o_mine, o_ref, steps, first):
+        for it in range(first, first + steps):
+            for i, (a, b) in enumerate(zip(mine, ref)):
+                g = torch.randn(a.shape, generator=gen) * (10.0 ** (i - 2))
+                skip = (i == 2 and it % 2 == 1) or i == 4          # tensor 4 never gets a gradient
+                a.grad = None if skip else g.clone()
+                b.grad = None if skip else g.clone()
+            o_mine.step()
+            o_ref.step()
+            if it == 2:
+                o_mine.param_groups[0]["lr"].fill_(1e-3)
+                o_ref.param_groups[0]["lr"] = 1e-3
+    run(opt, opt_ref, 5, 0)
+    # tensor 2 was skipped on odd steps: optim.Adam advanced ITS step counter only 3 times, the shared counter 5 times
+    # (bias corrections differ); the model never has such a tensor -- a parameter either always or never receives a gradient
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        if i != 2:
+            np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=2e-6, atol=1e-7)
+    assert float(opt.state[mine[0]]["step"]) == 5 and torch.equal(mine[4], ref[4])
+    sd = opt.state_dict()
+    opt2 = HipAdam(mine, lr=1e-3, betas=(0.9, 0.999))
+    opt2.load_state_dict(sd)
+    assert opt2.state[mine[3]]["exp_avg"].data_ptr() == opt2._m[3].data_ptr()     # still views of the flat allocation
+    assert torch.equal(opt2._moments, opt._moments) and float(opt2._step) == 5
+    before = [p.detach().clone() for p in mine]
+    for a in mine:
+        a.grad = torch.ones_like(a)
+    opt2.step()
+    assert all(not torch.equal(a, b) for a, b in zip(mine, before))
+
+
 def test_scalar_pack_and_train_loop(monkeypatch):
     torch_backend.install(monkeypatch)
     cfg = R.Cfg(img_size=64, class_dim=8, DIM_img=4, DIM_text=4, vocab_size=50, batch_size=4)

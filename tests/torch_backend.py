@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -19,7 +21,7 @@ OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_red
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
-            "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad"]
+            "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad", "adam_step"]
 
 
 def install(monkeypatch):
@@ -406,3 +408,24 @@ def embedding_bwd(ids, gout, vocab, padding_idx=0):
     d.index_add_(0, flat, gout.reshape(-1, gout.shape[-1]))
     d[padding_idx] = 0
     return d
+
+
+def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None):
+    """csrc/adam.hip: step += 1, then the fused-Adam arithmetic (moment updates and `+ eps` in double) per tensor"""
+    step += 1
+    s = float(step)
+    lr = float(lr)
+    bc1 = np.float32(1.0 - beta1 ** s)
+    bc2s = np.float32(np.sqrt(1.0 - beta2 ** s))
+    step_size = float(np.float32(lr / float(bc1)))
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        m, v = ms[i], vs[i]
+        g = g.reshape(-1).double()
+        m.copy_((beta1 * m.double() + (1.0 - beta1) * g).float())
+        v.copy_((beta2 * v.double() + (1.0 - beta2) * g * g).float())
+        denom = ((v.sqrt() / float(bc2s)).double() + eps).float()
+        p.data.view(-1).sub_(step_size * m / denom)
+        if lowp is not None and lowp[i] is not None:
+            lowp[i].view(-1).copy_(p.data.view(-1))
