@@ -110,6 +110,7 @@ class Bf16Weights:
         self.flat = None
         self.views = {}
         self.versions = None
+        self.synced_by_optimizer = False
 
     def _build(self):
         dev = self.mods[0].weight.device
@@ -127,11 +128,27 @@ class Bf16Weights:
         tensor's version counter moved (load_state_dict, manual edits)."""
         if self.flat is None or self.flat.device != self.mods[0].weight.device:
             self._build()
-        vers = (param_epoch(), [m.weight._version for m in self.mods])
+        if self.synced_by_optimizer:
+            # mimic_amd.optim.HipAdam rewrites the copies in the pass that updates the masters (and does not touch the
+            # tensors' version counters): only edits from outside (load_state_dict, another optimiser) need a refresh
+            force, vers = False, (None, [m.weight._version for m in self.mods])
+        else:
+            vers = (param_epoch(), [m.weight._version for m in self.mods])
         if force or vers != self.versions:
             with torch.no_grad():
                 torch._foreach_copy_([self.views[id(m)] for m in self.mods], [m.weight.detach() for m in self.mods])
             self.versions = vers
+
+    def bind_optimizer(self, on: bool):
+        """on: an optimiser keeps the copies in step with the masters from now on -> {id(master weight): flat bf16 view}"""
+        self.synced_by_optimizer = False
+        self.versions = None
+        if not on:
+            return {}
+        self.refresh(True)
+        self.synced_by_optimizer = True
+        self.versions = (None, [m.weight._version for m in self.mods])
+        return {id(m.weight): self.views[id(m)].view(-1) for m in self.mods}
 
     def get(self, mod):
         return self.views[id(mod)]

@@ -107,13 +107,25 @@ class HotPathExperiment:
         capturable = bool(capturable and fused)
         lr = self.flags.initial_learning_rate
         betas = (self.flags.beta_1, self.flags.beta_2)
+        shadows = [m._shadow for m in self.mm_vae.modules() if getattr(m, "_shadow", None) is not None]
         if capturable and os.environ.get("MOPOE_TORCH_ADAM", "0") != "1":
-            from ..optim import HipAdam
-            self.optimizer = HipAdam([p for p in params if p.requires_grad], lr=lr, betas=betas)
+            self.set_hip_adam(params, lr, betas, shadows)
             return
+        for sh in shadows:
+            sh.bind_optimizer(False)
         if capturable:
             lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
         self.optimizer = optim.Adam(params, lr=lr, betas=betas, fused=fused, capturable=capturable)
+
+    def set_hip_adam(self, params, lr, betas, shadows):
+        from ..optim import HipAdam
+        self.optimizer = HipAdam([p for p in params if p.requires_grad], lr=lr, betas=betas)
+        # bf16 family: the kernel that updates a master weight also rewrites its bf16 copy (no cast pass per step)
+        lowp = {}
+        for sh in shadows:
+            lowp.update(sh.bind_optimizer(True))
+        if lowp:
+            self.optimizer.lowp = [lowp.get(id(p)) for p in self.optimizer._params]
 
     def set_rec_weights(self):
         f = self.flags

@@ -308,6 +308,46 @@ def test_bf16_host_logic_matches_oracle_bf16_mode(monkeypatch):
     assert len(cos) > 150 and np.median(cos) > 0.995 and min(cos) > 0.9, (len(cos), np.median(cos), min(cos))
 
 
+def test_bf16_copies_kept_by_the_optimiser(monkeypatch):
+    """bf16 family: HipAdam rewrites the bf16 weight copies in the pass that updates the masters (no cast pass per step);
+    the copies follow the masters step by step, a load_state_dict or a foreign in-place edit still triggers a refresh,
+    and the trajectory equals the one with the per-forward cast (torch's Adam)."""
+    torch_backend.install(monkeypatch)
+    cfg = R.Cfg(img_size=64, class_dim=16, DIM_img=8, DIM_text=8, vocab_size=60, batch_size=5)
+    sd = R.init_state(cfg, seed=9)
+    batches = [R.synthetic_batch(cfg, 5, seed=10 + i) for i in range(3)]
+    eps = batches[0][1]
+    runs = {}
+    for kind in ("hip", "torch"):
+        exp = build_exp(cfg, {k: v.clone() for k, v in sd.items()}, "cpu", "train_nodrop", eps=eps, compute_dtype="bf16")
+        exp.flags.initial_learning_rate = 1e-3
+        if kind == "hip":
+            shadows = [m._shadow for m in exp.mm_vae.modules() if getattr(m, "_shadow", None) is not None]
+            assert len(shadows) == 6
+            exp.set_hip_adam(list(exp.mm_vae.parameters()), 1e-3, (0.9, 0.999), shadows)
+            assert sum(x is not None for x in exp.optimizer.lowp) == sum(len(sh.mods) for sh in shadows)
+        else:
+            exp.set_optimizer()
+        losses = []
+        for b in batches:
+            losses.append(RE.train_step(exp, (dict(b[0]), None))["total_loss"].item())
+            if kind == "hip":
+                for sh in shadows:
+                    assert sh.synced_by_optimizer
+                    for m in sh.mods:
+                        assert torch.equal(sh.get(m), m.weight.detach().to(torch.bfloat16)), type(m)
+        runs[kind] = losses
+        if kind == "hip":
+            sh = shadows[0]
+            with torch.no_grad():
+                sh.mods[0].weight.mul_(2.0)            # an edit the optimiser did not make
+            stale = sh.get(sh.mods[0]).clone()
+            sh.refresh(False)
+            assert not torch.equal(stale, sh.get(sh.mods[0]))
+            assert torch.equal(sh.get(sh.mods[0]), sh.mods[0].weight.detach().to(torch.bfloat16))
+    np.testing.assert_allclose(runs["hip"], runs["torch"], rtol=2e-4)
+
+
 @pytest.mark.parametrize("mode", ["eval", "train_nodrop", "train"])
 def test_g5_char_encoding_host_logic(monkeypatch, mode):
     """text_encoding='char' (reference mimic/networks/char_encoding/*.py): the product's char text networks -- state_dict keys
