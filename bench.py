@@ -153,7 +153,7 @@ def main():
     # at N = 1; at N > 1 forward + backward and Adam are two graphs with the RCCL all-reduce of the gradient arenas
     # (never captured) between them.  MOPOE_GRAPH=0 selects the eager step (RCCL overlapped with backward).
     use_graph = os.environ.get("MOPOE_GRAPH", "1") != "0"
-    exp.set_optimizer(capturable=use_graph)
+    exp.set_optimizer()   # mimic_amd.optim.HipAdam on the GPU (csrc/adam.hip), captured or eager
     reducer = GradAllReducer(exp.mm_vae, world, force=force_dp) if (world > 1 or force_dp) else None
     if reducer is not None:
         reducer.broadcast_parameters()
