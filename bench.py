@@ -244,8 +244,8 @@ def main():
         # second pass of the same steps, eager and on ONE stream, with HIP events around every implicit-GEMM launch:
         # inside the replayed graph single kernels cannot be bracketed, and with the side streams on a kernel's
         # events would also time whatever runs beside it.  (profiles/ holds the rocprofv3 stats of both regimes.)
-        from mimic_amd import mmvae as _mm, trunk as _tr
-        _mm.NET_STREAMS, _tr.WGRAD_SIDE_STREAM = False, False
+        from mimic_amd import lanes as _ln, trunk as _tr
+        _ln.NET_STREAMS, _tr.WGRAD_SIDE_STREAM = False, False
         run(2, start=args.warmup, eager=True)
         torch.cuda.synchronize()
         ops.prof_enable(True)

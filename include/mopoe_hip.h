@@ -380,6 +380,10 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
 #define MOPOE_PROF_KINDS 80
 int mopoe_prof_enable(int32_t on);
+/* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
+ * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without
+ * a profiler in the process (tests/tools/net_timeline.py). */
+int mopoe_prof_stamp(uint64_t* slot, void* stream);
 int mopoe_prof_collect(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes /* may be NULL */);
 
 #ifdef __cplusplus

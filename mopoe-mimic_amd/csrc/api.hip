@@ -63,9 +63,18 @@ ProfScope::~ProfScope() {
   (void)hipEventRecord(g_prof_pool[slot].stop, stream);
 }
 
+// one device timestamp (the 100 MHz constant clock) into *slot when the stream reaches this point
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
 }  // namespace mopoe
 
 using namespace mopoe;
+
+extern "C" int mopoe_prof_stamp(uint64_t* slot, void* stream) {
+  if (!slot) { set_error("prof_stamp: null slot"); return MOPOE_ERR_ARG; }
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+  return check_launch("prof_stamp");
+}
 
 extern "C" int mopoe_abi_version(void) { return MOPOE_ABI_VERSION; }
 

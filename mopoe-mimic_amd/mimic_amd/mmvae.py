@@ -21,58 +21,8 @@ from . import ops
 
 MOD_SLOT = {"PA": 0, "Lateral": 1, "text": 2}
 
-# The three encoders (and, after the latent kernel, the three decoders) are independent: each modality's
-# networks run on their own HIP stream so that their small layers (8x8, 4x4, 1x1 grids and the text trunk,
-# none of which fills 256 CUs) overlap with the other modalities' work.  Autograd replays each network's
-# backward on the stream its forward ran on.  MOPOE_NET_STREAMS=0 keeps everything on the caller's stream.
-NET_STREAMS = os.environ.get("MOPOE_NET_STREAMS", "1") != "0"
-# which modalities get a stream of their own (the others stay on the caller's stream).  Default: the two image
-# modalities fork, text runs in line -- one fork/join pair less per phase; measured +1.7 % over forking all three
-NET_STREAM_SET = set(os.environ.get("MOPOE_NET_STREAM_SET", "PA,Lateral").split(","))
-_net_streams: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
-
-
-class _ModalityLanes:
-    """fork(name) -> context running on that modality's stream after everything enqueued so far on the
-    caller's stream; join() makes the caller's stream wait for every forked lane."""
-
-    def __init__(self, device):
-        self.enabled = NET_STREAMS and device.type == "cuda"
-        self.used = []
-        if self.enabled:
-            self.device = device
-            self.main = torch.cuda.current_stream(device)
-            self.ev = torch.cuda.Event()
-            self.ev.record(self.main)
-
-    def fork(self, name):
-        if not self.enabled or name not in NET_STREAM_SET:
-            return contextlib.nullcontext()
-        key = (self.device.index if self.device.index is not None else torch.cuda.current_device(), name)
-        if key not in _net_streams:
-            _net_streams[key] = torch.cuda.Stream(device=self.device)
-        s = _net_streams[key]
-        s.wait_event(self.ev)
-        self.used.append(s)
-        return torch.cuda.stream(s)
-
-    def share(self, *tensors):
-        """tensors made on the caller's stream that the lanes read (caching-allocator bookkeeping)"""
-        if self.enabled:
-            for t in tensors:
-                if t is not None:
-                    for s in _net_streams.values():
-                        t.record_stream(s)
-
-    def join(self, *tensors):
-        """caller's stream waits for the lanes; `tensors` were made on a lane and are read by the caller"""
-        if self.enabled:
-            for s in self.used:
-                self.main.wait_stream(s)
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.main)
-            self.used = []
+from .nets import run_group
+from .lanes import NET_STREAMS, NET_STREAM_SET, ModalityLanes as _ModalityLanes, _net_streams  # noqa: F401
 
 
 def reweight_weights(w):
@@ -244,14 +194,11 @@ class VAEtrimodalMimic(BaseMMVae, nn.Module):
                    "joint_divergence": latents["_joint_divergence"].view(()),
                    "individual_divs": latents["_klds"], "dyn_prior": None}
         z = latents["_z"]
-        lanes = _ModalityLanes(z.device)
-        lanes.share(z)
-        dec = {}
-        for m_key, net in (("Lateral", self.decoder_lat), ("PA", self.decoder_pa), ("text", self.decoder_text)):
-            if m_key in self.modalities and input_batch[m_key] is not None:
-                with lanes.fork(m_key):
-                    dec[m_key] = net(None, z)
-        lanes.join(*[t for out in dec.values() for t in out if torch.is_tensor(t)])
+        # the decoders are independent: one grouped autograd node, each network on its modality's stream (nets.run_group)
+        items = [(m_key, net, (None, z))
+                 for m_key, net in (("Lateral", self.decoder_lat), ("PA", self.decoder_pa), ("text", self.decoder_text))
+                 if m_key in self.modalities and input_batch[m_key] is not None]
+        dec = dict(zip([m for m, _, _ in items], run_group(items)))
         rec = {}
         for m_key in self.modalities:
             if m_key not in dec:
@@ -267,20 +214,15 @@ class VAEtrimodalMimic(BaseMMVae, nn.Module):
 
     def encode(self, input_batch):
         latents = {}
-        lanes = None
+        items = []
         for name, enc in (("PA", self.encoder_pa), ("Lateral", self.encoder_lat), ("text", self.encoder_text)):
             if name in input_batch.keys():
-                x = input_batch[name]
-                if lanes is None:
-                    lanes = _ModalityLanes(x.device)
-                lanes.share(x)
-                with lanes.fork(name):
-                    latents[name] = list(enc(x))[:2]
+                items.append((name, enc, (input_batch[name],)))
             else:
                 latents[name + "_style"] = [None, None]
                 latents[name] = [None, None]
-        if lanes is not None:
-            lanes.join(*[t for v in latents.values() for t in v])
+        for (name, _, _), out in zip(items, run_group(items)):
+            latents[name] = list(out)[:2]
         return latents
 
     def get_random_styles(self, num_samples):

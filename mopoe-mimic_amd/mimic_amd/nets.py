@@ -17,7 +17,10 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
+from .lanes import ModalityLanes
 from .layout import Bf16Weights, BnParams, Indexed, PackedConv, ResBlockParams, param_epoch
 from .ops import Geom
 from .trunk import (BackwardArena, BlockSpec, MaskSource, StatsArena, apply_running_updates, stats_needed,
@@ -34,7 +37,11 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, n_in, *tensors):
         inputs = tensors[:n_in]
+        if ops.STAMPS is not None:
+            ops.stamp(f"{type(net).__name__}#{id(net) % 997} fwd begin")
         outs, saved = net._run_forward(*inputs)
+        if ops.STAMPS is not None:
+            ops.stamp(f"{type(net).__name__}#{id(net) % 997} fwd end")
         ctx.net, ctx.saved, ctx.n_in = net, saved, n_in
         ctx.in_needs_grad = [isinstance(t, torch.Tensor) and t.requires_grad for t in inputs]
         return outs if isinstance(outs, tuple) else (outs,)
@@ -44,7 +51,11 @@ class _NetFn(torch.autograd.Function):
         net = ctx.net
         from .plugins import is_zero_placeholder   # (a stride-0 zero gradient stays as it is: plugins.HeadCtx)
         gouts = [None if g is None else (g if is_zero_placeholder(g) else g.contiguous()) for g in gouts]
+        if ops.STAMPS is not None:
+            ops.stamp(f"{type(net).__name__}#{id(net) % 997} bwd begin")
         gin, grads, arena = net._run_backward(ctx.saved, ctx.in_needs_grad, *gouts)
+        if ops.STAMPS is not None:
+            ops.stamp(f"{type(net).__name__}#{id(net) % 997} bwd end")
         ctx.saved = None
         plist = [grads.get(name) for name, _ in net._named_param_list()]
         reducer = getattr(net, "_grad_reducer", None)
@@ -53,6 +64,107 @@ class _NetFn(torch.autograd.Function):
             # overlaps with the backward of the networks autograd has not reached yet
             reducer.network_done(arena, [g for g in plist if g is not None])
         return (None, None, *gin, *plist)
+
+
+class _GroupFn(torch.autograd.Function):
+    """Several independent networks (the three encoders, or the three decoders) as ONE autograd node.
+
+    forward(group, *tensors): tensors = for every network its inputs followed by its parameters.  Each network runs on
+    its modality's lane (lanes.ModalityLanes: fork from the caller's stream, join back) in the forward AND in the
+    backward.  With one node per network the autograd engine decides where each backward starts: measured with device
+    timestamps inside the replayed step (tests/tools/net_timeline.py), the second image decoder's backward began only
+    when the first one's had ended (3.95 ms for the three decoders' backward against 1.6 ms for their forward); with the
+    fork / join made here the backward has the forward's shape."""
+
+    @staticmethod
+    def forward(ctx, group, *tensors):
+        lanes = ModalityLanes(tensors[0].device)
+        outs_all, saved_all, needs_all, off = [], [], [], 0
+        order = sorted(range(len(group)), key=lambda i: group[i][1] != "text")     # the longest chain of small kernels first
+        spans = []
+        for net, name, n_in, n_par in group:
+            spans.append((off, off + n_in))
+            off += n_in + n_par
+        res = [None] * len(group)
+        for i in order:
+            net, name, n_in, n_par = group[i]
+            inputs = tensors[spans[i][0]:spans[i][1]]
+            lanes.share(*[t for t in inputs if torch.is_tensor(t)])
+            with lanes.fork(name):
+                if ops.STAMPS is not None:
+                    ops.stamp(f"{type(net).__name__}:{name} fwd begin")
+                outs, saved = net._run_forward(*inputs)
+                if ops.STAMPS is not None:
+                    ops.stamp(f"{type(net).__name__}:{name} fwd end")
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            res[i] = (outs, saved, [isinstance(t, torch.Tensor) and t.requires_grad for t in inputs])
+        lanes.join(*[t for r in res for t in r[0] if torch.is_tensor(t)])
+        ctx.group, ctx.saved, ctx.needs = group, [r[1] for r in res], [r[2] for r in res]
+        ctx.n_out = [len(r[0]) for r in res]
+        return tuple(t for r in res for t in r[0])
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from .plugins import is_zero_placeholder   # (a stride-0 zero gradient stays as it is: plugins.HeadCtx)
+        group = ctx.group
+        gouts = [None if g is None else (g if is_zero_placeholder(g) else g.contiguous()) for g in gouts]
+        dev = next(g.device for g in gouts if g is not None)
+        lanes = ModalityLanes(dev)
+        lanes.share(*[g for g in gouts if g is not None])
+        per, off = [], 0
+        for n in ctx.n_out:
+            per.append(gouts[off:off + n])
+            off += n
+        order = sorted(range(len(group)), key=lambda i: group[i][1] != "text")
+        res = [None] * len(group)
+        for i in order:
+            net, name, n_in, n_par = group[i]
+            with lanes.fork(name):
+                if ops.STAMPS is not None:
+                    ops.stamp(f"{type(net).__name__}:{name} bwd begin")
+                gin, grads, arena = net._run_backward(ctx.saved[i], ctx.needs[i], *per[i])
+                if ops.STAMPS is not None:
+                    ops.stamp(f"{type(net).__name__}:{name} bwd end")
+                plist = [grads.get(pname) for pname, _ in net._named_param_list()]
+                reducer = getattr(net, "_grad_reducer", None)
+                if reducer is not None:      # data parallelism: this network's gradients are complete (see _NetFn)
+                    reducer.network_done(arena, [g for g in plist if g is not None])
+            res[i] = (*gin, *plist)
+        ctx.saved = None
+        lanes.join(*[t for r in res for t in r if torch.is_tensor(t)])
+        return (None, *[t for r in res for t in r])
+
+
+GROUP_NODES = os.environ.get("MOPOE_GROUP_NODES", "1") != "0"    # (A/B switch: 0 = one autograd node per network)
+
+
+def run_group(items):
+    """items: [(lane name, network, forward arguments)] of independent networks -> [what network(*arguments) returns].
+    One autograd node for all of them (_GroupFn) when there is more than one."""
+    if len(items) < 2 or not GROUP_NODES:
+        lanes, outs = None, []
+        for name, net, args in items:
+            first = next(a for a in args if torch.is_tensor(a))
+            if lanes is None:
+                lanes = ModalityLanes(first.device)
+            lanes.share(*[a for a in args if torch.is_tensor(a)])
+            with lanes.fork(name):
+                outs.append(net(*args))
+        if lanes is not None:
+            lanes.join(*[t for o in outs for t in o if torch.is_tensor(t)])
+        return outs
+    group, tensors = [], []
+    for name, net, args in items:
+        inputs = net._group_inputs(*args)
+        params = [p for _, p in net._named_param_list()]
+        group.append((net, name, len(inputs), len(params)))
+        tensors += [*inputs, *params]
+    flat = _GroupFn.apply(group, *tensors)
+    outs, off = [], 0
+    for (name, net, args), n in zip(items, [len(net._out_names) for _, net, _ in items]):
+        outs.append(net._finish(tuple(flat[off:off + n])))
+        off += n
+    return outs
 
 
 def compute_dtype(flags):
@@ -206,9 +318,16 @@ class EncoderImg(_HipNet):
         assert h == 1
         self._init_dtype(flags, fp32_mods=[self.feature_extractor.conv1])
 
+    _out_names = ("mu", "logvar")
+
+    def _group_inputs(self, x_img):
+        return (x_img,)
+
+    def _finish(self, outs):
+        return outs[0], outs[1]
+
     def forward(self, x_img):
-        mu, lv = self._call(x_img)
-        return mu, lv
+        return self._finish(self._call(*self._group_inputs(x_img)))
 
     def _run_forward(self, x_img):
         self._begin_forward()
@@ -301,9 +420,16 @@ class DecoderImg(_HipNet):
             self._scale_cache[key] = t
         return self._scale_cache[key]
 
+    _out_names = ("img",)
+
+    def _group_inputs(self, z_style, z_content):
+        return (z_content,)
+
+    def _finish(self, outs):
+        return outs[0], self._scale(outs[0].device)
+
     def forward(self, z_style, z_content):
-        (img,) = self._call(z_content)
-        return img, self._scale(img.device)
+        return self._finish(self._call(*self._group_inputs(z_style, z_content)))
 
     def _run_forward(self, z):
         self._begin_forward()
@@ -400,9 +526,16 @@ class EncoderText(_HipNet):
         assert w == 1, "text encoder must reduce the sequence to length 1"
         self._init_dtype(flags)
 
+    _out_names = ("mu", "logvar")
+
+    def _group_inputs(self, x_text):
+        return (x_text,)
+
+    def _finish(self, outs):
+        return outs[0], outs[1]
+
     def forward(self, x_text):
-        mu, lv = self._call(x_text)
-        return mu, lv
+        return self._finish(self._call(*self._group_inputs(x_text)))
 
     def _run_forward(self, ids):
         self._begin_forward()
@@ -541,8 +674,16 @@ class DecoderText(_HipNet):
             return self.text_generator.conv2
         return self.text_generator.generator[len(self.text_generator.plan)]
 
+    _out_names = ("logp_pad",)
+
+    def _group_inputs(self, z_style, z_content):
+        return (z_content,)
+
     def forward(self, z_style, z_content):
-        (logp_pad,) = self._call(z_content)
+        return self._finish(self._call(*self._group_inputs(z_style, z_content)))
+
+    def _finish(self, outs):
+        (logp_pad,) = outs
         hc = getattr(self, "_head_ctx_latest", None)
         if hc is not None and logp_pad.requires_grad:
             logp_pad._mopoe_head_ctx = hc

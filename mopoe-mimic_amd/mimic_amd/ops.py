@@ -667,6 +667,25 @@ def bn_running_update(entries: Sequence, momentum=0.1):
     _check(lib().mopoe_bn_running_update(arr, len(entries), C.c_float(momentum), _stream()))
 
 
+# timeline stamps (tuning aid, tests/tools/net_timeline.py): when STAMPS is a dict, stamp(name) appends a device timestamp
+# taken when the current stream reaches this point; the launches are captured like any other node of the step
+STAMPS = None
+
+
+def stamp(name):
+    st = STAMPS
+    if st is None:
+        return
+    if "buf" not in st:
+        st["buf"] = torch.zeros(256, dtype=torch.int64, device="cuda")
+        st["names"] = []
+    i = len(st["names"])
+    if i >= st["buf"].numel():
+        return
+    st["names"].append(name)
+    _check(lib().mopoe_prof_stamp(C.c_void_p(st["buf"].data_ptr() + 8 * i), _stream()))
+
+
 def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None):
     """One Adam step over all tensors (header: mopoe_adam_step).  params / grads / ms / vs: equally long lists of fp32
     tensors (a grad may be None: that tensor is skipped, like optim.Adam does); step: device scalar (float), incremented;
