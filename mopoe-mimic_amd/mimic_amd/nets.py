@@ -80,7 +80,7 @@ class _GroupFn(torch.autograd.Function):
     def forward(ctx, group, *tensors):
         lanes = ModalityLanes(tensors[0].device)
         outs_all, saved_all, needs_all, off = [], [], [], 0
-        order = sorted(range(len(group)), key=lambda i: group[i][1] != "text")     # the longest chain of small kernels first
+        order = _group_order(group, 0)
         spans = []
         for net, name, n_in, n_par in group:
             spans.append((off, off + n_in))
@@ -115,7 +115,7 @@ class _GroupFn(torch.autograd.Function):
         for n in ctx.n_out:
             per.append(gouts[off:off + n])
             off += n
-        order = sorted(range(len(group)), key=lambda i: group[i][1] != "text")
+        order = _group_order(group, 1)
         res = [None] * len(group)
         for i in order:
             net, name, n_in, n_par = group[i]
@@ -133,6 +133,16 @@ class _GroupFn(torch.autograd.Function):
         ctx.saved = None
         lanes.join(*[t for r in res for t in r if torch.is_tensor(t)])
         return (None, *[t for r in res for t in r])
+
+
+# launch order inside a group, forward and backward: "first" = the text network (the longest chain of small kernels) is
+# enqueued first, "last" = after the image networks
+GROUP_TEXT = os.environ.get("MOPOE_GROUP_TEXT", "first,first").split(",")
+
+
+def _group_order(group, phase):
+    first = GROUP_TEXT[phase] == "first"
+    return sorted(range(len(group)), key=lambda i: (group[i][1] != "text") == first)
 
 
 GROUP_NODES = os.environ.get("MOPOE_GROUP_NODES", "1") != "0"    # (A/B switch: 0 = one autograd node per network)
