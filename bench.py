@@ -170,6 +170,8 @@ def main():
             graphed = RE.GraphedTrainStep(exp, batches[0], pack, reducer)
         except Exception as e:   # e.g. a runtime that refuses the capture: the eager step is always available
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
+            import traceback
+            traceback.print_exc()
             graphed, use_graph = None, False
             exp.set_optimizer(capturable=False)
     if world > 1 or force_dp:   # every rank must take the same path (graphed ranks issue their collectives at different points)

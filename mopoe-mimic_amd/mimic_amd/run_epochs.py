@@ -200,6 +200,12 @@ class GraphedTrainStep:
             #   graph 3  scatter of the bucket, Adam
             # other threads keep making HIP calls meanwhile (the process group's watchdog polls events): they must not
             # invalidate a capture, hence thread_local
+            # the process group's watchdog thread polls (hipEventQuery) the completion events of the warm-up steps'
+            # collectives every 100 ms until it has reaped them; a poll that lands inside a capture invalidated it in 2 of
+            # 12 runs (hipErrorStreamCaptureInvalidated, then an abort in the watchdog).  Let it reap them first: with no
+            # outstanding work it makes no HIP call.
+            torch.cuda.synchronize(dev)
+            time.sleep(0.35)
             model = exp.mm_vae
             dec_params = [p for n in ("decoder_pa", "decoder_lat", "decoder_text") for p in getattr(model, n).parameters()
                           if p.requires_grad]
