@@ -40,7 +40,11 @@ constexpr int BK = 16;            // K-chunk of the wgrad kernel and of the 64x6
 #define GEMM_8WAVES 1          // 512-thread blocks (8 waves, 64x32 per wave): 4 waves per SIMD hide the load/store phases
 #endif
 #ifndef PERSIST_BLOCKS
-#define PERSIST_BLOCKS 512   // upper bound on blocks of one launch (2 x 8-wave blocks per CU resident)
+// upper bound on blocks of one launch (each block walks the M tiles it owns).  512 = exactly the 2 x 8-wave blocks a CU
+// holds: fastest for a kernel that is alone on the chip, but inside the replayed step such a kernel keeps every CU for its
+// whole duration and the other branches' small kernels wait.  With 2048 blocks retire 4x as often: C2 step +1...2 %
+// (5250-5260 -> 5305-5370 samples/s; 4096: 5339, 16384: 5324); the bf16 family measured the other way and stays at 512.
+#define PERSIST_BLOCKS 2048
 #endif
 #ifndef GEMM_MIN_WAVES
 #define GEMM_MIN_WAVES 3

@@ -21,6 +21,10 @@
 // scalar fallback): K channels a multiple of 32, N channels a multiple of 8, 16-byte aligned tensors < 2 GiB.
 #include "gemm_common.hpp"
 
+#ifndef PERSIST_BLOCKS_BF16
+#define PERSIST_BLOCKS_BF16 512   // upper bound on blocks of one launch (see conv_gemm.hip: PERSIST_BLOCKS)
+#endif
+
 namespace mopoe {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -638,7 +642,7 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
     a.counters = (int*)ws;
     a.partial = (float*)((char*)ws + WS_COUNTER_BYTES);
   }
-  const long persist = cfg == 3 ? 512 : 768;
+  const long persist = cfg == 3 ? PERSIST_BLOCKS_BF16 : PERSIST_BLOCKS_BF16 * 3 / 2;   // 4-wave blocks: 3 per CU share
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   const double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
