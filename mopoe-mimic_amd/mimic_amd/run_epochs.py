@@ -181,15 +181,10 @@ class GraphedTrainStep:
         before = [m.pending_batches for m in bns]
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
-        dot = os.environ.get("MOPOE_GRAPH_DOT")      # tuning aid: the captured DAG as a .dot file (tests/tools/graph_dag.py)
-        if dot:
-            self.graph.enable_debug_mode()
         exp.optimizer.zero_grad(set_to_none=True)
         if self.reducer is None:
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.routine = train_step(exp, (dict(self.static), None), None, pack)
-            if dot:
-                self.graph.debug_dump(dot)
         else:
             # Data parallel: the step is THREE graphs on one memory pool, with the collectives (never captured) between
             # them, so that half of the gradient bytes are reduced while the device still computes:
