@@ -351,7 +351,8 @@ int mopoe_embedding_bwd_bf16(const float* ids, const uint16_t* gout, float* dtab
  * table has to be built or kept alive and a hipGraph capture bakes the pointers into its nodes).  g == NULL: the tensor
  * and its state are left untouched (optim.Adam skips parameters whose .grad is None).  p16 (optional): the bf16 copy of
  * the updated parameter is written in the same pass (the bf16 family's MFMA operands).
- * step: device scalar (float), incremented first.  lr_dev: device scalar or NULL (then `lr`).  coef: float[2] device scratch.
+ * step: device scalar (float), incremented first (NULL: a further part of a step whose counter and coefficients an
+ * earlier call with nseg >= 0 has already set in `coef`: the tensors of one step may be updated by several calls).  lr_dev: device scalar or NULL (then `lr`).  coef: float[2] device scratch.
  * The hyper-parameters are doubles, as in optim.Adam: 1 - beta2 formed from the float 0.999 is off by 1.3e-5 relative. */
 typedef struct {
   float* p;

@@ -121,10 +121,12 @@ using namespace mopoe;
 
 extern "C" int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const float* lr_dev, double lr,
                                double beta1, double beta2, double eps, float* coef, void* stream) {
-  if (!segs || nseg < 0 || !step || !coef) { set_error("adam_step: bad arguments"); return MOPOE_ERR_ARG; }
+  if ((!segs && nseg != 0) || nseg < 0 || !coef) { set_error("adam_step: bad arguments"); return MOPOE_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, st, step, lr_dev, lr, beta1, beta2, coef);
-  if (int rc = check_launch("adam_prep")) return rc;
+  if (step) {   // (step == NULL: a further part of a step whose counter and coefficients an earlier call has set)
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, st, step, lr_dev, lr, beta1, beta2, coef);
+    if (int rc = check_launch("adam_prep")) return rc;
+  }
   int32_t i = 0;
   while (i < nseg) {
     AdamPack pack;

@@ -129,6 +129,8 @@ class _GroupFn(torch.autograd.Function):
                 reducer = getattr(net, "_grad_reducer", None)
                 if reducer is not None:      # data parallelism: this network's gradients are complete (see _NetFn)
                     reducer.network_done(arena, [g for g in plist if g is not None])
+                elif EARLY_STEP[0] is not None:   # (run_epochs.train_step: this network's optimiser update on its own lane)
+                    EARLY_STEP[0]([p for _, p in net._named_param_list()], plist)
             res[i] = (*gin, *plist)
         ctx.saved = None
         lanes.join(*[t for r in res for t in r if torch.is_tensor(t)])
@@ -143,6 +145,9 @@ GROUP_TEXT = os.environ.get("MOPOE_GROUP_TEXT", "first,first").split(",")
 def _group_order(group, phase):
     first = GROUP_TEXT[phase] == "first"
     return sorted(range(len(group)), key=lambda i: (group[i][1] != "text") == first)
+
+
+EARLY_STEP = [None]    # callable(params, grads) while a train step that updates per network is in its backward
 
 
 GROUP_NODES = os.environ.get("MOPOE_GROUP_NODES", "1") != "0"    # (A/B switch: 0 = one autograd node per network)

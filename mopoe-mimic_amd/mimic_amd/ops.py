@@ -686,7 +686,7 @@ def stamp(name):
     _check(lib().mopoe_prof_stamp(C.c_void_p(st["buf"].data_ptr() + 8 * i), _stream()))
 
 
-def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None):
+def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None, prep=True):
     """One Adam step over all tensors (header: mopoe_adam_step).  params / grads / ms / vs: equally long lists of fp32
     tensors (a grad may be None: that tensor is skipped, like optim.Adam does); step: device scalar (float), incremented;
     lr: float or device scalar; coef: float[2] device scratch; lowp: optional list of bf16 copies (or None entries)
@@ -705,7 +705,7 @@ def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=Non
         arr[i] = _AdamSeg(p_.data_ptr(), g_.data_ptr(), ms[i].data_ptr(), vs[i].data_ptr(),
                           None if lp is None else lp.data_ptr(), p_.numel())
     lr_dev = lr if isinstance(lr, torch.Tensor) else None
-    _check(lib().mopoe_adam_step(arr, n, _p(step), _p(lr_dev), C.c_double(0.0 if lr_dev is not None else float(lr)),
+    _check(lib().mopoe_adam_step(arr, n, _p(step) if prep else None, _p(lr_dev), C.c_double(0.0 if lr_dev is not None else float(lr)),
                                  C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _p(coef), _stream()))
 
 

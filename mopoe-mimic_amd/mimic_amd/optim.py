@@ -35,8 +35,37 @@ class HipAdam(torch.optim.Optimizer):
         self._m = [self._moments[0, o:o + p.numel()] for o, p in zip(offs, self._params)]
         self._v = [self._moments[1, o:o + p.numel()] for o, p in zip(offs, self._params)]
         self.lowp = None       # optional: per-parameter bf16 copies rewritten by the same kernel (list aligned with params)
+        self._index = {id(p): i for i, p in enumerate(self._params)}
+        self._early = None     # indices already updated in the current step (early_begin / early_step)
         for p, m, v in zip(self._params, self._m, self._v):
             self.state[p] = dict(step=self._step, exp_avg=m.view_as(p), exp_avg_sq=v.view_as(p))
+
+    def _launch(self, idx, grads, prep):
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        pick = lambda xs: [xs[i] for i in idx]
+        ops.adam_step(pick(self._params), grads, pick(self._m), pick(self._v), self._step, group["lr"], b1, b2, group["eps"],
+                      self._coef, lowp=None if self.lowp is None else pick(self.lowp), prep=prep)
+
+    @torch.no_grad()
+    def early_begin(self):
+        """a step in parts: advance the step counter now (current stream); early_step() then updates tensors whose gradients
+        are final while the rest of the backward still runs, step() the remaining ones"""
+        self._launch([], [], True)
+        self._early = set()
+
+    @torch.no_grad()
+    def early_step(self, params, grads):
+        idx, gs = [], []
+        for p, g in zip(params, grads):
+            i = self._index.get(id(p))
+            if i is None or g is None or i in self._early:
+                continue
+            idx.append(i)
+            gs.append(g if g.is_contiguous() else g.contiguous())
+        if idx:
+            self._launch(idx, gs, False)
+            self._early.update(idx)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -44,16 +73,18 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        group = self.param_groups[0]
-        grads = []
-        for p in self._params:
+        early, self._early = self._early, None
+        idx, grads = [], []
+        for i, p in enumerate(self._params):
+            if early is not None and i in early:
+                continue
             g = p.grad
             if g is not None and not g.is_contiguous():
                 g = g.contiguous()
+            idx.append(i)
             grads.append(g)
-        b1, b2 = group["betas"]
-        ops.adam_step(self._params, grads, self._m, self._v, self._step, group["lr"], b1, b2, group["eps"], self._coef,
-                      lowp=self.lowp)
+        if early is None or any(g is not None for g in grads):
+            self._launch(idx, grads, early is None)
         return loss
 
     def load_state_dict(self, state_dict):

@@ -185,11 +185,27 @@ def test_hip_adam_host_logic(monkeypatch):
         if i != 2:
             np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=2e-6, atol=1e-7)
     assert float(opt.state[mine[0]]["step"]) == 5 and torch.equal(mine[4], ref[4])
+    # a step in parts (run_epochs.train_step: every network's tensors right behind its backward) equals a step in one piece
+    for a, b in list(zip(mine, ref))[:4]:
+        g = torch.randn(a.shape, generator=gen)
+        a.grad, b.grad = g.clone(), g.clone()
+    mine[4].grad = ref[4].grad = None
+    opt.early_begin()
+    opt.early_step(mine[:2], [p.grad for p in mine[:2]])
+    opt.early_step(mine[1:4], [p.grad for p in mine[1:4]])      # (tensor 1 again: ignored the second time)
+    opt.step()                                                   # what is left: tensor 4, without a gradient
+    opt_ref.step()
+    assert float(opt.state[mine[0]]["step"]) == 6 and opt._early is None
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        if i != 2:
+            np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=2e-6, atol=1e-7)
+    for a in mine:
+        a.grad = None
     sd = opt.state_dict()
     opt2 = HipAdam(mine, lr=1e-3, betas=(0.9, 0.999))
     opt2.load_state_dict(sd)
     assert opt2.state[mine[3]]["exp_avg"].data_ptr() == opt2._m[3].data_ptr()     # still views of the flat allocation
-    assert torch.equal(opt2._moments, opt._moments) and float(opt2._step) == 5
+    assert torch.equal(opt2._moments, opt._moments) and float(opt2._step) == 6
     before = [p.detach().clone() for p in mine]
     for a in mine:
         a.grad = torch.ones_like(a)

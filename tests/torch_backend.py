@@ -410,9 +410,10 @@ def embedding_bwd(ids, gout, vocab, padding_idx=0):
     return d
 
 
-def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None):
-    """csrc/adam.hip: step += 1, then the fused-Adam arithmetic (moment updates and `+ eps` in double) per tensor"""
-    step += 1
+def adam_step(params, grads, ms, vs, step, lr, beta1, beta2, eps, coef, lowp=None, prep=True):
+    """csrc/adam.hip: step += 1 (prep), then the fused-Adam arithmetic (moment updates and `+ eps` in double) per tensor"""
+    if prep:
+        step += 1
     s = float(step)
     lr = float(lr)
     bc1 = np.float32(1.0 - beta1 ** s)
