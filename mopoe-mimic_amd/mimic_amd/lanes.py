@@ -33,6 +33,10 @@ class ModalityLanes:
             self.ev = torch.cuda.Event()
             self.ev.record(self.main)
 
+    def forks(self, name):
+        """does `name` get a stream of its own (False: it runs in line on the caller's stream)"""
+        return self.enabled and name in NET_STREAM_SET
+
     def fork(self, name):
         if not self.enabled or name not in NET_STREAM_SET:
             return contextlib.nullcontext()

@@ -130,7 +130,7 @@ class _GroupFn(torch.autograd.Function):
                 if reducer is not None:      # data parallelism: this network's gradients are complete (see _NetFn)
                     reducer.network_done(arena, [g for g in plist if g is not None])
                 elif EARLY_STEP[0] is not None:   # (run_epochs.train_step: this network's optimiser update on its own lane)
-                    EARLY_STEP[0]([p for _, p in net._named_param_list()], plist)
+                    EARLY_STEP[0]([p for _, p in net._named_param_list()], plist, inline=not lanes.forks(name))
             res[i] = (*gin, *plist)
         ctx.saved = None
         lanes.join(*[t for r in res for t in r if torch.is_tensor(t)])

@@ -37,6 +37,7 @@ class HipAdam(torch.optim.Optimizer):
         self.lowp = None       # optional: per-parameter bf16 copies rewritten by the same kernel (list aligned with params)
         self._index = {id(p): i for i, p in enumerate(self._params)}
         self._early = None     # indices already updated in the current step (early_begin / early_step)
+        self._held = None      # an in-line network's update waiting for the next in-line network
         for p, m, v in zip(self._params, self._m, self._v):
             self.state[p] = dict(step=self._step, exp_avg=m.view_as(p), exp_avg_sq=v.view_as(p))
 
@@ -52,10 +53,13 @@ class HipAdam(torch.optim.Optimizer):
         """a step in parts: advance the step counter now (current stream); early_step() then updates tensors whose gradients
         are final while the rest of the backward still runs, step() the remaining ones"""
         self._launch([], [], True)
-        self._early = set()
+        self._early, self._held = set(), None
 
     @torch.no_grad()
-    def early_step(self, params, grads):
+    def early_step(self, params, grads, inline=False):
+        """inline: the network ran on the caller's stream, where the next phase of the backward is waiting behind it (the
+        text decoder in front of the latent node): its update is held back until the next in-line network is done (the
+        text encoder, behind which the caller's stream only waits for the other lanes) or until step()."""
         idx, gs = [], []
         for p, g in zip(params, grads):
             i = self._index.get(id(p))
@@ -63,9 +67,17 @@ class HipAdam(torch.optim.Optimizer):
                 continue
             idx.append(i)
             gs.append(g if g.is_contiguous() else g.contiguous())
+        self._early.update(idx)
+        if inline and self._held is None:
+            # (aliases, not the tensors themselves: a second reference to a gradient the node is about to return would
+            # make AccumulateGrad clone it instead of adopting the arena view)
+            self._held = (idx, [g.detach() for g in gs])
+            return
+        if inline and self._held is not None:
+            idx, gs = self._held[0] + idx, self._held[1] + gs
+            self._held = None
         if idx:
             self._launch(idx, gs, False)
-            self._early.update(idx)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -74,6 +86,9 @@ class HipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         early, self._early = self._early, None
+        held, self._held = getattr(self, "_held", None), None
+        if held is not None and held[0]:
+            self._launch(held[0], held[1], False)
         idx, grads = [], []
         for i, p in enumerate(self._params):
             if early is not None and i in early:
