@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- MoPoE joint-ELBO train step on MI355X (BASELINE.json metric: samples/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c5] [--no-cpu-baseline]
-    N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-                --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2d128|c1|c3|c5] [--no-cpu-baseline]
+    N > 1:  either  python bench.py --gpus N ...   (no WORLD_SIZE in the environment: bench.py starts N fresh rank
+                    processes itself, before anything in this process has touched a GPU -- the reference's launcher does
+                    the same with mp.spawn, mimic/main_mimic.py:44-48,65-69)
+            or      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                        --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = run_epochs.train's loop body (reference mimic/run_epochs.py:122-142) on one synthetic batch
 already resident in HBM: forward (3 encoders, fused latent kernel, 3 decoders, likelihoods), loss,
@@ -19,11 +22,14 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      the dominant kernel (fp32-MFMA implicit-GEMM) timed with HIP events on its launch stream
                 in a second pass of the same steps (so the events do not perturb `value`)
   cpu_baseline  the CPU oracle (oracle/mopoe_ref.py, a port) timed on this host's cores on a bounded
-                sample (1 warm-up + 3 timed steps of the same workload on 16 threads, ~30 s of CPU work).
+                sample (3 warm-up + 10 timed steps of the default workload on 16 threads, ~45 s of CPU work;
+                scaled down for the larger configurations).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +43,7 @@ CONFIGS = {
     # name: (img_size, class_dim, DIM_img, per-GPU batch, compute dtype)
     "c1": (64, 64, 64, 8, "fp32"),
     "c2": (128, 128, 64, 64, "fp32"),         # BASELINE config #2 (and #4 per GPU): the default / headline workload
+    "c2d128": (128, 128, 128, 64, "fp32"),    # secondary point of SURVEY 8d: the flag default DIM_img = 128 (flags.py:61)
     "c3": (128, 128, 64, 256, "bf16"),        # BASELINE config #3
     "c5": (256, 256, 64, 32, "bf16"),         # BASELINE config #5 (per GPU)
     "c5f32": (256, 256, 64, 32, "fp32"),      # config #5's shape in fp32
@@ -48,7 +55,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 # conv/linear FLOPs per sample per train step (fwd + dgrad + wgrad) and algorithmic bytes per sample
 # (3 passes x (in + out) elements x element size)
-FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c3": 13.58e9, "c5": 42.63e9, "c5f32": 42.63e9, "c2b256": 13.58e9}
+FLOPS_PER_SAMPLE = {"c1": 5.78e9, "c2": 13.58e9, "c2d128": 48.05e9, "c3": 13.58e9, "c5": 42.63e9, "c5f32": 42.63e9,
+                    "c2b256": 13.58e9}
 BYTES_PER_SAMPLE = {"c3": 55.0e6, "c5": 193.0e6}
 
 
@@ -64,10 +72,12 @@ def synthetic_batches(flags, n, device, seed):
     return out
 
 
-def cpu_baseline(cfg_name, steps=3, threads=None):
+def cpu_baseline(cfg_name, steps=10, warmup=3, threads=None):
     """CPU restatement (oracle) of the same train step on this host: fwd + autograd bwd + Adam.  Threads: the box's
     CPU share for one GPU (16) unless the host has fewer cores -- 128 oversubscribed threads were SLOWER than the
-    reference's own 8-thread figure."""
+    reference's own 8-thread figure.  Sample: BASELINE.md section 3's >= 3 warm-up + >= 10 timed
+    steps at the default workload (~45 s of CPU work), scaled down by the workload's cost for the larger configurations
+    (never below 1 + 1)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import mopoe_ref as R
     host_cores = os.cpu_count() or 1
@@ -84,20 +94,57 @@ def cpu_baseline(cfg_name, steps=3, threads=None):
             v.data.zero_()
     params = [v for v in sd.values() if v.is_floating_point() and v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-5)
-    # bounded sample: about 3 steps of the default workload's cost (~10-30 s of CPU work), at least one timed step
-    steps = max(1, min(steps, round(steps * FLOPS_PER_SAMPLE["c2"] * 64 / (FLOPS_PER_SAMPLE[cfg_name] * bsz))))
+    rel = FLOPS_PER_SAMPLE["c2"] * 64 / (FLOPS_PER_SAMPLE[cfg_name] * bsz)     # cost of a c2 step / cost of this step
+    steps = max(1, min(steps, round(steps * rel)))
+    warmup = max(1, min(warmup, round(warmup * rel)))
     times = []
-    for i in range(steps + 1):
+    for i in range(warmup + steps):
         batch, eps = R.synthetic_batch(cfg, bsz, seed=100 + i)
         t0 = time.perf_counter()
         R.adam_train_step(cfg, sd, opt, batch, eps, R.Ctx("train", draw_masks=True))
         times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / steps
+    t = sum(times[warmup:]) / steps
     return {"value": bsz / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "host_cores": host_cores,
             "kind": "port",
-            "sample": f"{steps} timed steps (after 1 warm-up) of the same workload (B={bsz}, fp32) through "
+            "sample": f"{steps} timed steps (after {warmup} warm-up) of the same workload (B={bsz}, fp32) through "
                       f"oracle/mopoe_ref.py on {torch.get_num_threads()} threads: fwd + autograd bwd + Adam, {t:.2f} s/step "
-                      f"(per step: {', '.join(f'{x:.2f}' for x in times[1:])} s)"}
+                      f"(per step: {', '.join(f'{x:.2f}' for x in times[warmup:])} s)"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes, one per GPU, started BEFORE this process has
+    made any GPU call (it never makes one: importing torch and parsing flags do not initialise HIP), as the reference's
+    Main does with mp.spawn (mimic/main_mimic.py:44-48,65-69).  A process that has initialised the GPU is never re-exec'd.
+    Rank 0 prints the JSON line on the inherited stdout; the exit code is the worst of the ranks'."""
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:      # a dead rank leaves its peers waiting in a collective: end exactly those PIDs
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -106,11 +153,15 @@ def main():
     ap.add_argument("--steps", type=int, default=100)    # >= 20 warm-up + >= 100 timed steps
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--lr", type=float, default=None, help="Adam step size (default: the reference's 5e-4, leomed_mimic_config.json:20)")
+    ap.add_argument("--lr", type=float, default=None,
+                    help="Adam step size (default 1e-5: at the reference's 5e-4, leomed_mimic_config.json:20, the reference "
+                         "arithmetic itself diverges on uniform-random images, profiles/r02_oracle_lr_divergence.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,10 +204,10 @@ def main():
     # at N = 1; at N > 1 forward + backward and Adam are two graphs with the RCCL all-reduce of the gradient arenas
     # (never captured) between them.  MOPOE_GRAPH=0 selects the eager step (RCCL overlapped with backward).
     use_graph = os.environ.get("MOPOE_GRAPH", "1") != "0"
-    exp.set_optimizer()   # mimic_amd.optim.HipAdam on the GPU (csrc/adam.hip), captured or eager
     reducer = GradAllReducer(exp.mm_vae, world, force=force_dp) if (world > 1 or force_dp) else None
     if reducer is not None:
-        reducer.broadcast_parameters()
+        reducer.broadcast_parameters()   # (before the optimiser: the bf16 weight copies it binds are cast from rank 0's values)
+    exp.set_optimizer()   # mimic_amd.optim.HipAdam on the GPU (csrc/adam.hip), captured or eager
     batches = synthetic_batches(flags, 4, device, seed=1 + rank)
     pack = RE.ScalarPack(device)
     torch.manual_seed(1234 + rank)
@@ -172,14 +223,13 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
             import traceback
             traceback.print_exc()
-            graphed, use_graph = None, False
-            exp.set_optimizer(capturable=False)
+            graphed, use_graph = None, False   # (the optimiser stays: HipAdam also steps eagerly, and its state has
+            #                                      already seen the set-up steps)
     if world > 1 or force_dp:   # every rank must take the same path (graphed ranks issue their collectives at different points)
         ok = torch.tensor([1.0 if graphed is not None else 0.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, async_op=True).wait()   # (asynchronous: mimic_amd/parallel.py, docstring)
         if use_graph and ok.item() < 0.5:
             graphed, use_graph = None, False
-            exp.set_optimizer(capturable=False)
 
     def run(nsteps, start=0, eager=False):
         for i in range(nsteps):
@@ -197,10 +247,14 @@ def main():
         host_done[0] = time.perf_counter()   # everything enqueued; the GPU may still be working
         return pack.read()
 
+    fence_token = torch.zeros(1, device=device)
+
     def fence():
         torch.cuda.synchronize()
         if world > 1 or force_dp:
-            dist.barrier()
+            # (a barrier made of an ASYNCHRONOUS collective + wait: mimic_amd/parallel.py explains why no synchronous
+            # collective is issued anywhere in this process)
+            dist.all_reduce(fence_token, async_op=True).wait()
             torch.cuda.synchronize()
 
     # device warm-up (not part of the W warm-up steps and not model work): a GPU that has just left idle needs
@@ -224,7 +278,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1 or force_dp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
         elapsed = float(t.item())
     samples = bsz * world * args.steps
     value = samples / elapsed
@@ -292,9 +346,11 @@ def main():
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
-                        "flops_per_launch": fl / n,
+                        "flops_per_launch": fl / n, "bytes_per_launch": by / n,
+                        "algorithmic_gbs": round(by / (ms * 1e-3) / 1e9, 1),
                         "all_gemm_kernels": {"ms_per_step": round(all_ms / nprof, 3),
                                              "achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),
+                                             "algorithmic_gbs": round(all_by / (all_ms * 1e-3) / 1e9, 1),
                                              "per_kernel_ms_per_step": {k: round(v[1] / nprof, 3) for k, v in prof.items()}}}
 
     cpu = None
@@ -306,6 +362,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "samples/sec", "value": round(value, 2), "unit": "samples/sec", "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if cdtype == "bf16" else "f32", "data": "synthetic",
@@ -326,7 +383,14 @@ def main():
                        **({"model_algorithmic_gbs": round(BYTES_PER_SAMPLE[args.config] * value / 1e9, 1),
                            "model_frac_of_hbm_peak": round(BYTES_PER_SAMPLE[args.config] * value / 1e9 / (HBM_PEAK_GBS * world), 4)}
                           if args.config in BYTES_PER_SAMPLE else {}),
-                       "last_total_loss": scalars.get("total_loss"), "lr": lr},
+                       # the 18 logged scalars (ELBO loss, 7 KLs, 3 NLLs, ...) are all-reduced across the ranks every step
+                       # and reported as the MEAN over ranks (each rank normalises by its own batch);
+                       # the north-star's cross-GPU ELBO SUM is that mean times the number of ranks
+                       "cross_rank_elbo": "mean",
+                       "last_total_loss": scalars.get("total_loss"),
+                       "last_total_loss_sum_over_ranks": (scalars.get("total_loss") * world
+                                                          if scalars.get("total_loss") is not None else None),
+                       "lr": lr},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

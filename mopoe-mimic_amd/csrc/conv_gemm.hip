@@ -1190,8 +1190,10 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
     const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
+    // algorithmic bytes: one read of the gathered activation + one write of the result
+    const double abytes = ((double)g->N * a.Hx * a.Wx * Ck + (double)a.rows_total * Cn) * sizeof(float);
     ProfScope prof(stream, flops, cfg >= 8 ? PROF_DIRECT + (cfg - 8) * 4 + spec
-                                           : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg));
+                                           : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
     // specialised main loops (spec != 0): vector path with Ck a multiple of the K chunk (every layer of the four
     // networks except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
@@ -1340,7 +1342,9 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   const int spec = a.fast ? (a.bn_in.mode != 0 ? 2 : 1) : 0;
-  ProfScope prof(stream, flops, vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1));
+  const double abytes = ((double)g->N * g->Hs * g->Ws * (g->transposed ? g->Cin : g->Cout)
+                         + (double)g->N * g->Hb * g->Wb * (g->transposed ? g->Cout : g->Cin)) * sizeof(float);   // both operands, once
+  ProfScope prof(stream, flops, vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1), abytes);
   dim3 grid(nI * nJ, taps, (unsigned)split);
   if (vec) {
     if (big) {

@@ -9,10 +9,34 @@
 
 namespace mopoe {
 
+// The row loop of every kernel below: a block owns chunks of U * rpp consecutive rows; a thread first issues the loads of
+// all its U rows of a chunk (U x streams 16-byte loads in flight per lane: HBM latency is hidden by bytes in flight, and at
+// 8-16 waves per CU one row per thread leaves the chip at a third of its bandwidth), then computes and stores them.  Rows
+// past the end are loaded from the last row (a valid address) and dropped.
+template <int VEC>
+__device__ __forceinline__ void ld_maskv(const float* p, float (&m)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+      m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = p[e];
+  }
+}
+__device__ __forceinline__ const float* mask_row(const mopoe_mask_ref& mask, long r, int C) {
+  if (mask.kind == 1) return mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
+  if (mask.kind == 2) return mask.mask + r * C;
+  return nullptr;
+}
+
 // ---- out = a*bn(s) + b*m  (+ stats of out) -----------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* s, const T* m, T* out, long rows,
-                                                                 int C, mopoe_bn_ref bn, float a, float b, double* stats) {
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* __restrict__ s, const T* __restrict__ m,
+                                                                 T* __restrict__ out, long rows, int C, mopoe_bn_ref bn,
+                                                                 float a, float b, double* stats) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
@@ -24,16 +48,28 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* s, c
       if (active && c < C) { const BnC k = bn_coef(bn, c); sc[e] = a * k.scale; sh[e] = a * k.shift; }
     }
     if (active) {
-      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const long off = r * C + (long)cv * VEC;
-        const VecT<T, VEC> vs = VecT<T, VEC>::ld(s + off), vm = VecT<T, VEC>::ld(m + off);
-        VecT<T, VEC> o;
-        for (int e = 0; e < VEC; ++e) {
-          o.v[e] = stored<T>(fmaf(vs.v[e], sc[e], sh[e]) + b * vm.v[e]);
-          part[0][e] += o.v[e];
-          part[1][e] += o.v[e] * o.v[e];
+      const long step = (long)gridDim.x * L.rpp * U;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw vs[U], vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          const long off = (r < rows ? r : rows - 1) * C + (long)cv * VEC;
+          vs[u] = VecT<T, VEC>::ldr(s + off); vm[u] = VecT<T, VEC>::ldr(m + off);
         }
-        o.st(out + off);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          if (r >= rows) break;
+          const VecT<T, VEC> ws = VecT<T, VEC>::un(vs[u]), wm = VecT<T, VEC>::un(vm[u]);
+          VecT<T, VEC> o;
+          for (int e = 0; e < VEC; ++e) {
+            o.v[e] = stored<T>(fmaf(ws.v[e], sc[e], sh[e]) + b * wm.v[e]);
+            part[0][e] += o.v[e];
+            part[1][e] += o.v[e] * o.v[e];
+          }
+          o.st(out + r * C + (long)cv * VEC);
+        }
       }
     }
     if (stats) {
@@ -45,9 +81,9 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* s, c
 }
 
 // ---- sums += {sum g, sum g*shat} -----------------------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* g, const T* s, long rows, int C,
-                                                                 mopoe_bn_ref bn, double* sums) {
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ s, long rows,
+                                                                 int C, mopoe_bn_ref bn, double* sums) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
@@ -59,12 +95,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* g, c
       if (active && c < C) { const BnC k = bn_coef(bn, c); mean[e] = k.mean; rstd[e] = k.rstd; }
     }
     if (active) {
-      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const long off = r * C + (long)cv * VEC;
-        const VecT<T, VEC> vg = VecT<T, VEC>::ld(g + off), vs = VecT<T, VEC>::ld(s + off);
-        for (int e = 0; e < VEC; ++e) {
-          part[0][e] += vg.v[e];
-          part[1][e] += vg.v[e] * ((vs.v[e] - mean[e]) * rstd[e]);
+      const long step = (long)gridDim.x * L.rpp * U;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw vg[U], vs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          const long off = (r < rows ? r : rows - 1) * C + (long)cv * VEC;
+          vg[u] = VecT<T, VEC>::ldr(g + off); vs[u] = VecT<T, VEC>::ldr(s + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (rb + (long)u * L.rpp >= rows) break;
+          const VecT<T, VEC> wg = VecT<T, VEC>::un(vg[u]), ws = VecT<T, VEC>::un(vs[u]);
+          for (int e = 0; e < VEC; ++e) {
+            part[0][e] += wg.v[e];
+            part[1][e] += wg.v[e] * ((ws.v[e] - mean[e]) * rstd[e]);
+          }
         }
       }
     }
@@ -75,11 +122,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* g, c
 }
 
 // ---- dm = b*g*mask ; ds = a*BNbwd(g; s) ---------------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* g, const T* s, T* dm, T* ds,
-                                                                 long rows, int C, mopoe_bn_ref bn, const double* sums,
-                                                                 mopoe_mask_ref mask, float a, float b, float* dgamma,
-                                                                 float* dbeta, float* colsum_dm, float* colsum_ds) {
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* __restrict__ g, const T* __restrict__ s,
+                                                                 T* __restrict__ dm, T* __restrict__ ds, long rows, int C,
+                                                                 mopoe_bn_ref bn, const double* sums, mopoe_mask_ref mask,
+                                                                 float a, float b, float* dgamma, float* dbeta,
+                                                                 float* colsum_dm, float* colsum_ds) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
@@ -99,23 +147,37 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* g, c
       }
     }
     if (active) {
-      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const long off = r * C + (long)cv * VEC;
-        const VecT<T, VEC> vg = VecT<T, VEC>::ld(g + off), vs = VecT<T, VEC>::ld(s + off);
-        VecT<T, VEC> om, os;
-        const float* mrow = nullptr;
-        if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
-        else if (mask.kind == 2) mrow = mask.mask + r * C;
-        for (int e = 0; e < VEC; ++e) {
-          const float mk = mrow ? mrow[cv * VEC + e] : 1.f;
-          om.v[e] = stored<T>(b * vg.v[e] * mk);
-          const float shat = (vs.v[e] - mean[e]) * rstd[e];
-          os.v[e] = stored<T>(gr[e] * (vg.v[e] - k1[e] - shat * k2[e]));
-          part[0][e] += om.v[e];
-          part[1][e] += os.v[e];
+      const long step = (long)gridDim.x * L.rpp * U;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw vg[U], vs[U];
+        float mk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          const long rc = r < rows ? r : rows - 1;
+          const long off = rc * C + (long)cv * VEC;
+          vg[u] = VecT<T, VEC>::ldr(g + off); vs[u] = VecT<T, VEC>::ldr(s + off);
+          const float* mrow = mask_row(mask, rc, C);
+          if (mrow) ld_maskv<VEC>(mrow + cv * VEC, mk[u]);
+          else for (int e = 0; e < VEC; ++e) mk[u][e] = 1.f;
         }
-        om.st(dm + off);
-        os.st(ds + off);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          if (r >= rows) break;
+          const VecT<T, VEC> wg = VecT<T, VEC>::un(vg[u]), ws = VecT<T, VEC>::un(vs[u]);
+          VecT<T, VEC> om, os;
+          for (int e = 0; e < VEC; ++e) {
+            om.v[e] = stored<T>(b * wg.v[e] * mk[u][e]);
+            const float shat = (ws.v[e] - mean[e]) * rstd[e];
+            os.v[e] = stored<T>(gr[e] * (wg.v[e] - k1[e] - shat * k2[e]));
+            part[0][e] += om.v[e];
+            part[1][e] += os.v[e];
+          }
+          const long off = r * C + (long)cv * VEC;
+          om.st(dm + off);
+          os.st(ds + off);
+        }
       }
     }
     if (colsum_dm || colsum_ds) {
@@ -130,11 +192,12 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* g, c
 // NEXT: dx is the gradient entering the previous residual block, whose first backward step is the pair of column
 // reductions {sum dx, sum dx * shat} over its shortcut output s (bn_bwd_reduce).  Producing them here saves that
 // kernel and its re-read of dx.
-template <typename T, int VEC, bool NEXT>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* dy, const T* x, const T* add,
-                                                                T* dx, long rows, int C, mopoe_bn_ref bn,
-                                                                const double* sums, mopoe_mask_ref mask, float* dgamma,
-                                                                float* dbeta, float* colsum_dx, const T* next_s,
+template <typename T, int VEC, bool NEXT, int U>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const T* __restrict__ add, T* __restrict__ dx, long rows,
+                                                                int C, mopoe_bn_ref bn, const double* sums,
+                                                                mopoe_mask_ref mask, float* dgamma, float* dbeta,
+                                                                float* colsum_dx, const T* __restrict__ next_s,
                                                                 mopoe_bn_ref next_bn, double* next_sums) {
   constexpr int NACC = NEXT ? 3 : 1;
   const ColLayout L(C, VEC);
@@ -158,26 +221,41 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* dy, c
       }
     }
     if (active) {
-      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const long off = r * C + (long)cv * VEC;
-        const VecT<T, VEC> vd = VecT<T, VEC>::ld(dy + off), vx = VecT<T, VEC>::ld(x + off);
-        VecT<T, VEC> va, vs, o;
-        if (add) va = VecT<T, VEC>::ld(add + off);
-        if (NEXT) vs = VecT<T, VEC>::ld(next_s + off);
-        const float* mrow = nullptr;
-        if (mask.kind == 1) mrow = mask.mask + (long)((unsigned)r / (unsigned)mask.rows_per_sample) * C;
-        else if (mask.kind == 2) mrow = mask.mask + r * C;
-        for (int e = 0; e < VEC; ++e) {
-          const float xhat = (vx.v[e] - mean[e]) * rstd[e];
-          float v = gr[e] * (vd.v[e] - k1[e] - xhat * k2[e]);
-          if (mrow) v *= mrow[cv * VEC + e];
-          if (add) v += va.v[e];
-          v = stored<T>(v);
-          o.v[e] = v;
-          part[0][e] += v;
-          if constexpr (NEXT) { part[1][e] += v; part[2][e] += v * ((vs.v[e] - nmean[e]) * nrstd[e]); }
+      const long step = (long)gridDim.x * L.rpp * U;
+      const bool has_mask = mask.kind != 0;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw vd[U], vx[U], va[U], vs[U];
+        float mk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          const long rc = r < rows ? r : rows - 1;
+          const long off = rc * C + (long)cv * VEC;
+          vd[u] = VecT<T, VEC>::ldr(dy + off); vx[u] = VecT<T, VEC>::ldr(x + off);
+          if (add) va[u] = VecT<T, VEC>::ldr(add + off);
+          if (NEXT) vs[u] = VecT<T, VEC>::ldr(next_s + off);
+          if (has_mask) ld_maskv<VEC>(mask_row(mask, rc, C) + cv * VEC, mk[u]);
         }
-        o.st(dx + off);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          if (r >= rows) break;
+          const VecT<T, VEC> wd = VecT<T, VEC>::un(vd[u]), wx = VecT<T, VEC>::un(vx[u]);
+          VecT<T, VEC> wa, ws, o;
+          if (add) wa = VecT<T, VEC>::un(va[u]);
+          if (NEXT) ws = VecT<T, VEC>::un(vs[u]);
+          for (int e = 0; e < VEC; ++e) {
+            const float xhat = (wx.v[e] - mean[e]) * rstd[e];
+            float v = gr[e] * (wd.v[e] - k1[e] - xhat * k2[e]);
+            if (has_mask) v *= mk[u][e];
+            if (add) v += wa.v[e];
+            v = stored<T>(v);
+            o.v[e] = v;
+            part[0][e] += v;
+            if constexpr (NEXT) { part[1][e] += v; part[2][e] += v * ((ws.v[e] - nmean[e]) * nrstd[e]); }
+          }
+          o.st(dx + r * C + (long)cv * VEC);
+        }
       }
     }
     if constexpr (NEXT) {
@@ -195,8 +273,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* dy, c
 }
 
 // ---- column sums -----------------------------------------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const T* x, float* out, long rows, int C) {
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const T* __restrict__ x, float* out, long rows, int C) {
   const ColLayout L(C, VEC);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
@@ -204,9 +282,20 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const T* x, float* o
     float part[1][VEC];
     for (int e = 0; e < VEC; ++e) part[0][e] = 0.f;
     if (active) {
-      for (long r = (long)blockIdx.x * L.rpp + L.tr; r < rows; r += (long)gridDim.x * L.rpp) {
-        const VecT<T, VEC> v = VecT<T, VEC>::ld(x + r * C + (long)cv * VEC);
-        for (int e = 0; e < VEC; ++e) part[0][e] += v.v[e];
+      const long step = (long)gridDim.x * L.rpp * U;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          v[u] = VecT<T, VEC>::ldr(x + (r < rows ? r : rows - 1) * C + (long)cv * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (rb + (long)u * L.rpp >= rows) break;
+          const VecT<T, VEC> w = VecT<T, VEC>::un(v[u]);
+          for (int e = 0; e < VEC; ++e) part[0][e] += w.v[e];
+        }
       }
     }
     double* const od[1] = {nullptr};
@@ -245,6 +334,18 @@ using namespace mopoe;
 template <typename T> struct EwVec { static constexpr int wide = 4; };
 template <> struct EwVec<bf16_t> { static constexpr int wide = 8; };
 
+// rows a thread has in flight per loop iteration (MOPOE_EW_UNROLL = 1 | 2 | 4, read once; tests/tools/glue_time.py sweeps it)
+static inline int ew_unroll() {
+  static const int u = ew_env("MOPOE_EW_UNROLL", 4);
+  return u >= 4 ? 4 : (u >= 2 ? 2 : 1);
+}
+#define EW_DISPATCH_U(LAUNCH_)       \
+  switch (ew_unroll()) {             \
+    case 4: LAUNCH_(4); break;       \
+    case 2: LAUNCH_(2); break;       \
+    default: LAUNCH_(1); break;      \
+  }
+
 template <typename T>
 static bool ew_wide_ok(int C, std::initializer_list<const void*> ptrs, const char* what, int* rc) {
   const bool ok = vec_ok(C, ptrs, EwVec<T>::wide);
@@ -263,10 +364,11 @@ static int block_out_fwd_t(const T* s, const T* m, T* out, int64_t rows, int32_t
   hipStream_t st = (hipStream_t)stream;
   int rc;
   constexpr int W = EwVec<T>::wide;
-  if (ew_wide_ok<T>(C, {s, m, out}, "block_out_fwd", &rc))
-    hipLaunchKernelGGL((block_out_fwd_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+#define MOPOE_L(U_) hipLaunchKernelGGL((block_out_fwd_kernel<T, W, U_>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats)
+  if (ew_wide_ok<T>(C, {s, m, out}, "block_out_fwd", &rc)) { EW_DISPATCH_U(MOPOE_L) }
+#undef MOPOE_L
   else if constexpr (std::is_same<T, float>::value)
-    hipLaunchKernelGGL((block_out_fwd_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
+    hipLaunchKernelGGL((block_out_fwd_kernel<float, 1, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, s, m, out, (long)rows, C, *bn_s, a, b, out_stats);
   else return rc;
   return check_launch("block_out_fwd");
 }
@@ -278,10 +380,11 @@ static int bn_bwd_reduce_t(const T* g, const T* s, int64_t rows, int32_t C, cons
   hipStream_t st = (hipStream_t)stream;
   int rc;
   constexpr int W = EwVec<T>::wide;
-  if (ew_wide_ok<T>(C, {g, s}, "bn_bwd_reduce", &rc))
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+#define MOPOE_L(U_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, W, U_>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums)
+  if (ew_wide_ok<T>(C, {g, s}, "bn_bwd_reduce", &rc)) { EW_DISPATCH_U(MOPOE_L) }
+#undef MOPOE_L
   else if constexpr (std::is_same<T, float>::value)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, (long)rows, C, *bn_s, sums);
   else return rc;
   return check_launch("bn_bwd_reduce");
 }
@@ -296,10 +399,11 @@ static int block_out_bwd_t(const T* g, const T* s, T* dm, T* ds, int64_t rows, i
   hipStream_t st = (hipStream_t)stream;
   int rc;
   constexpr int W = EwVec<T>::wide;
-  if (ew_wide_ok<T>(C, {g, s, dm, ds}, "block_out_bwd", &rc))
-    hipLaunchKernelGGL((block_out_bwd_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+#define MOPOE_L(U_) hipLaunchKernelGGL((block_out_bwd_kernel<T, W, U_>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds)
+  if (ew_wide_ok<T>(C, {g, s, dm, ds, mk.mask}, "block_out_bwd", &rc)) { EW_DISPATCH_U(MOPOE_L) }
+#undef MOPOE_L
   else if constexpr (std::is_same<T, float>::value)
-    hipLaunchKernelGGL((block_out_bwd_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
+    hipLaunchKernelGGL((block_out_bwd_kernel<float, 1, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, g, s, dm, ds, (long)rows, C, *bn_s, sums, mk, a, b, dgamma, dbeta, colsum_dm, colsum_ds);
   else return rc;
   return check_launch("block_out_bwd");
 }
@@ -318,12 +422,16 @@ static int bn_bwd_apply_t(const T* dy, const T* x, const T* add, T* dx, int64_t 
   hipStream_t st = (hipStream_t)stream;
   int rc;
   constexpr int W = EwVec<T>::wide;
-  const bool vec = ew_wide_ok<T>(C, {dy, x, add, dx, next_s}, "bn_bwd_apply", &rc);
+  const bool vec = ew_wide_ok<T>(C, {dy, x, add, dx, next_s, mk.mask}, "bn_bwd_apply", &rc);
   if (!vec && !std::is_same<T, float>::value) return rc;
   const dim3 grid(ew_grid(rows, C, vec ? W : 1)), blk(EW_THREADS);
-#define MOPOE_APPLY(V_, N_) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, N_>), grid, blk, 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx, next_s, nb, next_sums)
-  if (vec) { if (next) MOPOE_APPLY(W, true); else MOPOE_APPLY(W, false); }
-  else if constexpr (std::is_same<T, float>::value) { if (next) MOPOE_APPLY(1, true); else MOPOE_APPLY(1, false); }
+#define MOPOE_APPLY(V_, N_, U_) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, N_, U_>), grid, blk, 0, st, dy, x, add, dx, (long)rows, C, *bn, sums, mk, dgamma, dbeta, colsum_dx, next_s, nb, next_sums)
+#define MOPOE_LN(U_) MOPOE_APPLY(W, true, U_)
+#define MOPOE_LP(U_) MOPOE_APPLY(W, false, U_)
+  if (vec) { if (next) { EW_DISPATCH_U(MOPOE_LN) } else { EW_DISPATCH_U(MOPOE_LP) } }
+  else if constexpr (std::is_same<T, float>::value) { if (next) MOPOE_APPLY(1, true, 1); else MOPOE_APPLY(1, false, 1); }
+#undef MOPOE_LN
+#undef MOPOE_LP
 #undef MOPOE_APPLY
   return check_launch("bn_bwd_apply");
 }
@@ -335,10 +443,11 @@ static int colsum_t(const T* x, float* out, int64_t rows, int32_t C, int32_t out
   if (!out_is_zero && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { set_error("colsum memset failed"); return MOPOE_ERR_LAUNCH; }
   int rc;
   constexpr int W = EwVec<T>::wide;
-  if (ew_wide_ok<T>(C, {x}, "colsum", &rc))
-    hipLaunchKernelGGL((colsum_kernel<T, W>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+#define MOPOE_L(U_) hipLaunchKernelGGL((colsum_kernel<T, W, U_>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C)
+  if (ew_wide_ok<T>(C, {x}, "colsum", &rc)) { EW_DISPATCH_U(MOPOE_L) }
+#undef MOPOE_L
   else if constexpr (std::is_same<T, float>::value)
-    hipLaunchKernelGGL((colsum_kernel<float, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
+    hipLaunchKernelGGL((colsum_kernel<float, 1, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C);
   else return rc;
   return check_launch("colsum");
 }

@@ -15,23 +15,28 @@ struct VecT;
 template <>
 struct VecT<float, 4> {
   float v[4];
-  __device__ static VecT ld(const float* p) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    VecT r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
-  }
+  typedef float4 Raw;     // what a load leaves in registers until the row is computed (ldr / un)
+  __device__ static Raw ldr(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  __device__ static VecT un(const Raw& t) { VecT r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+  __device__ static VecT ld(const float* p) { return un(ldr(p)); }
   __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <>
 struct VecT<float, 1> {
   float v[1];
+  typedef float Raw;
+  __device__ static Raw ldr(const float* p) { return *p; }
+  __device__ static VecT un(const Raw& t) { VecT r; r.v[0] = t; return r; }
   __device__ static VecT ld(const float* p) { VecT r; r.v[0] = *p; return r; }
   __device__ void st(float* p) const { *p = v[0]; }
 };
 template <>
 struct VecT<bf16_t, 8> {   // 16 bytes per lane
   float v[8];
-  __device__ static VecT ld(const bf16_t* p) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+  typedef uint4 Raw;
+  __device__ static Raw ldr(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static VecT ld(const bf16_t* p) { return un(ldr(p)); }
+  __device__ static VecT un(const Raw& t) {
     VecT r;
     r.v[0] = bf16_lo(t.x); r.v[1] = bf16_hi(t.x); r.v[2] = bf16_lo(t.y); r.v[3] = bf16_hi(t.y);
     r.v[4] = bf16_lo(t.z); r.v[5] = bf16_hi(t.z); r.v[6] = bf16_lo(t.w); r.v[7] = bf16_hi(t.w);
@@ -44,10 +49,12 @@ struct VecT<bf16_t, 8> {   // 16 bytes per lane
 template <>
 struct VecT<bf16_t, 4> {   // 8 bytes per lane (edge kernels: 16 lanes x 4 channels per pixel)
   float v[4];
-  __device__ static VecT ld(const bf16_t* p) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
+  typedef uint2 Raw;
+  __device__ static Raw ldr(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  __device__ static VecT un(const Raw& t) {
     VecT r; r.v[0] = bf16_lo(t.x); r.v[1] = bf16_hi(t.x); r.v[2] = bf16_lo(t.y); r.v[3] = bf16_hi(t.y); return r;
   }
+  __device__ static VecT ld(const bf16_t* p) { return un(ldr(p)); }
   __device__ void st(bf16_t* p) const { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])); }
 };
 template <int VEC>

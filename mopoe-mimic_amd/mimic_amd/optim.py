@@ -4,7 +4,16 @@ mimic/run_epochs.py:131) on one HIP kernel family (csrc/adam.hip) instead of PyT
 Same interface as torch.optim.Adam for what the hot path and its callers use: param_groups (a ReduceLROnPlateau scheduler
 fills the device-resident learning rate in place), state[p] = {step, exp_avg, exp_avg_sq}, state_dict / load_state_dict,
 zero_grad, step.  The two moments of all tensors live in one allocation; the step counter is one device scalar shared
-by all tensors (optim.Adam keeps one per tensor, all equal), so the whole step is capturable in a hipGraph."""
+by all tensors (optim.Adam keeps one per tensor, all equal), so the whole step is capturable in a hipGraph.
+
+ASSUMPTION (documented difference from torch.optim.Adam): every parameter handed to the optimiser receives a gradient
+on every step it takes part in.  optim.Adam advances a tensor's own step only when it has a gradient, so a parameter whose
+gradient is None on SOME steps (a modality missing from some batches) would get a different bias correction there; here a
+tensor without a gradient is skipped (its moments stay) but the shared counter advances.  On the hot path the set of
+gradient-less parameters is fixed for a run (the word encoder's unused resblock_7/8): those are never updated by either
+optimiser, and `check_uniform_grads` raises the first time a parameter's has-gradient state CHANGES between steps.
+early_begin() advances the counter before the backward: a backward that raises leaves the counter one ahead with no
+update applied (the run is over at that point: OOM -> new process, main_mimic.Main)."""
 from __future__ import annotations
 
 import torch
@@ -36,6 +45,7 @@ class HipAdam(torch.optim.Optimizer):
         self._v = [self._moments[1, o:o + p.numel()] for o, p in zip(offs, self._params)]
         self.lowp = None       # optional: per-parameter bf16 copies rewritten by the same kernel (list aligned with params)
         self._index = {id(p): i for i, p in enumerate(self._params)}
+        self._had_grad = None  # per-parameter has-gradient pattern of the first eager step (check_uniform_grads)
         self._early = None     # indices already updated in the current step (early_begin / early_step)
         self._held = None      # an in-line network's update waiting for the next in-line network
         for p, m, v in zip(self._params, self._m, self._v):
@@ -47,6 +57,18 @@ class HipAdam(torch.optim.Optimizer):
         pick = lambda xs: [xs[i] for i in idx]
         ops.adam_step(pick(self._params), grads, pick(self._m), pick(self._v), self._step, group["lr"], b1, b2, group["eps"],
                       self._coef, lowp=None if self.lowp is None else pick(self.lowp), prep=prep)
+
+    def check_uniform_grads(self):
+        """eager steps only (host-side, no device work): the has-gradient pattern must not change between steps (see the
+        module docstring); the captured step cannot change it by construction"""
+        pattern = [p.grad is not None for p in self._params]
+        if self._had_grad is None:
+            self._had_grad = pattern
+        elif pattern != self._had_grad:
+            i = next(k for k, (a, b) in enumerate(zip(pattern, self._had_grad)) if a != b)
+            raise RuntimeError(f"HipAdam: parameter #{i} {'gained' if pattern[i] else 'lost'} its gradient between steps; the "
+                               "shared step counter would give it a different bias correction than torch.optim.Adam "
+                               "(use MOPOE_TORCH_ADAM=1 for runs whose set of trained parameters varies)")
 
     @torch.no_grad()
     def early_begin(self):
@@ -87,6 +109,8 @@ class HipAdam(torch.optim.Optimizer):
                 loss = closure()
         early, self._early = self._early, None
         held, self._held = getattr(self, "_held", None), None
+        if not (self._params[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.check_uniform_grads()
         if held is not None and held[0]:
             self._launch(held[0], held[1], False)
         idx, grads = [], []
@@ -105,13 +129,17 @@ class HipAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """the loaded moments are copied INTO the flat allocation (the kernel's records point there)"""
         super().load_state_dict(state_dict)
-        step = None
+        steps = set()
         for p, m, v in zip(self._params, self._m, self._v):
             st = self.state.get(p, {})
             if "exp_avg" in st and st["exp_avg"].data_ptr() != m.data_ptr():
                 m.copy_(st["exp_avg"].reshape(-1))
                 v.copy_(st["exp_avg_sq"].reshape(-1))
-                step = st.get("step", step)
+                if "step" in st:
+                    steps.add(float(st["step"]))
             self.state[p] = dict(step=self._step, exp_avg=m.view_as(p), exp_avg_sq=v.view_as(p))
-        if step is not None:
-            self._step.fill_(float(step))
+        if len(steps) > 1:
+            raise ValueError(f"HipAdam.load_state_dict: the loaded tensors carry different step counts {sorted(steps)}; this "
+                             "optimiser keeps ONE step counter (see the module docstring)")
+        if steps:
+            self._step.fill_(steps.pop())

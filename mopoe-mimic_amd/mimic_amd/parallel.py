@@ -17,6 +17,16 @@ start.  Differences by design:
   * BatchNorm running statistics are not re-broadcast every forward (train-mode arithmetic never reads
     them) but on demand (``sync_buffers``) before evaluation / checkpointing;
   * the per-step scalar pack is averaged across ranks in the same step (north-star: cross-GPU ELBO).
+
+EVERY collective issued here is asynchronous (async_op=True) and then waited for on the caller's stream.  This is a
+correctness rule, not a preference: since PyTorch 2.7 a SYNCHRONOUS collective runs on the caller's current stream and
+records its completion event there; the process group's watchdog thread polls that event (hipEventQuery) every 100 ms
+until it has reaped the work, and the HIP runtime answers a query of an event whose stream is capturing AT THE TIME OF
+THE QUERY with hipErrorCapturedEvent -- even when the event was recorded long before the capture began -- which ends the
+watchdog with an exception (process abort) and invalidates the capture, in every capture_error_mode
+(profiles/r03_capture_watchdog_probe.txt, tests/tools/capture_watchdog_probe.py: `ncclsync_*` and `query_capstream`).
+An asynchronous collective's events live on the process group's own stream, which never captures, so no event of the
+process group is ever recorded on a stream that run_epochs.GraphedTrainStep later captures.
 """
 from __future__ import annotations
 
@@ -55,14 +65,34 @@ class GradAllReducer:
         if not self.active:
             return
         with torch.no_grad():
-            for t in list(self.module.parameters()) + list(self.module.buffers()):
-                dist.broadcast(t, src)
+            works = [dist.broadcast(t, src, async_op=True)
+                     for t in list(self.module.parameters()) + list(self.module.buffers())]
+            for w in works:
+                w.wait()
+        # a broadcast writes the tensors without bumping their version counters: derived copies (bf16 weight shadows,
+        # the padded vocabulary head) must not trust the counters across it
+        from .layout import note_params_changed
+        note_params_changed()
+        for m in self.module.modules():
+            sh = getattr(m, "_shadow", None)
+            if sh is not None:
+                sh.versions = None
+
+    def all_agree(self, ok: bool) -> bool:
+        """True iff `ok` on every rank (one MIN all-reduce; blocking: the caller branches on the answer)"""
+        if not self.active:
+            return bool(ok)
+        dev = next(self.module.parameters()).device
+        t = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True).wait()
+        return bool(t.item() > 0.5)
 
     def sync_buffers(self, src: int = 0):
         if not self.active:
             return
-        for b in self.module.buffers():
-            dist.broadcast(b, src)
+        works = [dist.broadcast(b, src, async_op=True) for b in self.module.buffers()]
+        for w in works:
+            w.wait()
 
     def _launch(self, t: torch.Tensor):
         op = self._avg if self._avg is not None else dist.ReduceOp.SUM
@@ -152,7 +182,7 @@ class GradAllReducer:
 
     def mean_scalars(self, packed: torch.Tensor) -> torch.Tensor:
         if self._avg is not None:
-            dist.all_reduce(packed, op=self._avg)
+            dist.all_reduce(packed, op=self._avg, async_op=True).wait()
             return packed
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, async_op=True).wait()
         return packed / self.world_size

@@ -181,7 +181,10 @@ class GraphedTrainStep:
     """
 
     def __init__(self, exp, example_batch, pack: typing.Optional[ScalarPack] = None,
-                 reducer: typing.Optional["GradAllReducer"] = None, warmup: int = 2):
+                 reducer: typing.Optional["GradAllReducer"] = None, warmup: int = 2,
+                 progress: typing.Optional[dict] = None):
+        """progress: if given, progress['eager_steps'] counts the set-up's eager train steps as they complete, so a caller
+        whose capture then fails knows whether the batch has already been trained on."""
         from .layout import BnParams
         self.exp, self.pack = exp, pack
         self.reducer = reducer if (reducer is not None and reducer.active) else None
@@ -192,6 +195,8 @@ class GraphedTrainStep:
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 train_step(exp, (dict(self.static), None), self.reducer, pack)
+                if progress is not None:
+                    progress["eager_steps"] = progress.get("eager_steps", 0) + 1
         self.stream.synchronize()
         bns = [m for m in exp.mm_vae.modules() if isinstance(m, BnParams)]
         before = [m.pending_batches for m in bns]
@@ -209,14 +214,15 @@ class GraphedTrainStep:
             #   graph 2  backward of the three encoders; gradients outside the arenas gathered into one staging bucket
             #            -> all-reduce of the encoder arenas and of the bucket (exposed), wait for everything
             #   graph 3  scatter of the bucket, Adam
-            # other threads keep making HIP calls meanwhile (the process group's watchdog polls events): they must not
-            # invalidate a capture, hence thread_local
-            # the process group's watchdog thread polls (hipEventQuery) the completion events of the warm-up steps'
-            # collectives every 100 ms until it has reaped them; a poll that lands inside a capture invalidated it in 2 of
-            # 12 runs (hipErrorStreamCaptureInvalidated, then an abort in the watchdog).  Let it reap them first: with no
-            # outstanding work it makes no HIP call.
-            torch.cuda.synchronize(dev)
-            time.sleep(0.35)
+            # Other threads keep making HIP calls meanwhile (the process group's watchdog polls the completion events of
+            # earlier collectives every 100 ms): capture_error_mode="thread_local" keeps their calls from counting as
+            # "unsafe calls during a capture".  What no mode tolerates on this HIP runtime is a query of an event whose
+            # stream is capturing at the time of the query (hipErrorCapturedEvent, also for events recorded BEFORE the
+            # capture began): round 2's 2-in-12 abort was the watchdog polling the completion event of a SYNCHRONOUS
+            # collective of the warm-up steps (the scalar pack's all-reduce), which PyTorch >= 2.7 runs -- and records -- on
+            # the caller's stream, i.e. on this capture stream (profiles/r03_capture_watchdog_probe.txt).  Every collective of
+            # mimic_amd.parallel is now asynchronous: its events live on the process group's own stream, so nothing the
+            # watchdog polls can sit on a capturing stream, whenever it polls.  No sleep, no timing assumption.
             model = exp.mm_vae
             dec_params = [p for n in ("decoder_pa", "decoder_lat", "decoder_text") for p in getattr(model, n).parameters()
                           if p.requires_grad]
@@ -310,17 +316,30 @@ class _StepRunner:
         batch_d = {k: v.to(self.exp.flags.device, non_blocking=True) for k, v in batch[0].items()}
         sig = _batch_signature(batch_d)
         if self.graphed is None and self.graph_allowed() and sig[0][1][0] == self.exp.flags.batch_size:
+            progress, err = {"eager_steps": 0}, None
             try:
                 # (its set-up runs eager steps on this batch: they are ordinary optimiser steps of the epoch)
-                self.graphed = GraphedTrainStep(self.exp, (batch_d, None), self.pack, self.reducer, warmup=1)
-                self.signature = sig
-                self.n_eager += 1
-                return
+                self.graphed = GraphedTrainStep(self.exp, (batch_d, None), self.pack, self.reducer, warmup=1, progress=progress)
             except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
                 if isinstance(e, torch.cuda.OutOfMemoryError) or str(e).startswith(("HIP out of memory", "CUDA out of memory")):
                     raise
+                self.graphed, err = None, e
+            # data parallel: graphed and eager ranks issue their collectives at different points of the step, so the ranks
+            # agree on ONE form (all of them drop to the eager step if any rank's capture failed)
+            ok = self.graphed is not None
+            if self.reducer is not None and self.reducer.active:
+                ok = self.reducer.all_agree(ok)
+            if not ok:
                 self.failed, self.graphed = True, None
-                warnings.warn(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eager steps")
+                why = f"{type(err).__name__}: {err}" if err is not None else "another rank's capture failed"
+                warnings.warn(f"hipGraph capture of the train step failed ({why}); running eager steps")
+            else:
+                self.signature = sig
+            if progress["eager_steps"] > 0:
+                # the set-up has already trained on this batch (optimiser step and, data parallel, its collectives
+                # included): running it again would train twice on it and, on one rank only, unpair every later collective
+                self.n_eager += 1
+                return
         if self.graphed is not None and sig == self.signature:
             self.graphed((batch_d, None))
             self.n_graphed += 1
@@ -471,13 +490,14 @@ def run_epochs(rank, exp) -> typing.List[dict]:
     if args.device.type == "cuda":
         torch.cuda.set_device(args.device)
     exp.mm_vae = exp.mm_vae.to(args.device)
-    exp.set_optimizer()
     reducer = None
     if getattr(args, "distributed", False):
         if not dist.is_initialized():
             set_up_process_group(args.world_size, _rank_of(rank))
         reducer = GradAllReducer(exp.mm_vae, args.world_size)
         reducer.broadcast_parameters()
+    # (after the broadcast: the optimiser binds the bf16 weight copies, which are cast from the values it finds)
+    exp.set_optimizer()
     from .dataio.MimicDataset import DeviceResidentMimic, Mimic
     resident = (isinstance(exp.dataset_train, Mimic) and args.device.type == "cuda"
                 and getattr(args, "device_resident_data", True) and not getattr(args, "weighted_sampler", False))
