@@ -84,8 +84,9 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 //   direct (LDS-free) gather: 44 + (tile - 8) * 4 + spec                           kinds 44..59
 //   bf16 gather:          60 + tile * 3 + (spec - 1)     (tile 0..4, spec 1..3)    kinds 60..74
 //   bf16 wgrad:           75 + (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)          kinds 75..78
+//   bf16 gather, LDS-DMA: 80 + (tile - 5) * 2 + (input gradient ? 1 : 0)           kinds 80..93
 enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44,
-       PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_NKINDS = MOPOE_PROF_KINDS };
+       PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_BF16_GLDS = 80, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {
   hipStream_t stream;
   int slot;

@@ -360,6 +360,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
 #include "gemm_colstats_rows.inc"
 }
 
+#include "conv_gemm_bf16_glds.inc"
+
 // =====================================================================================================
 // weight gradient: dWp[tap][ci][co] (fp32) = sum over pixels of T(x)[pixel][ci] * dy[pixel][co]
 // K = pixels is the strided index of BOTH operands: both tiles are staged [pixel][channel] as they lie in memory and
@@ -552,6 +554,10 @@ static int ilog2_exact(long v) {
 }
 
 // tiles: 0 = 128x128 (4 waves)  1 = 256x64 (4 waves)  2 = 64x64 (4 waves)  3 = 256x128 (8 waves)  4 = 128x64 (4 waves)
+// LDS-DMA family (conv_gemm_bf16_glds.inc; operands without a transform on load, K channels a multiple of 64):
+//   5 = 128x128, 2 buffers   6 = 128x128, 3 buffers   7 = 256x128 (8 waves), 2 buffers   8 = 256x128, 3 buffers
+//   9 = 128x64, 2 buffers   10 = 128x64, 3 buffers   11 = 256x64 (8 waves as 4x2... see GLDS_TILES), 3 buffers
+constexpr int BF16_NTILES = 12;
 static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bias, void* Y, int out_f32,
                               const mopoe_conv_geom* g, int dest_on_small, int Ck, int Cn, int w_nk,
                               const mopoe_bn_ref* bn_in, const mopoe_mask_ref* mask, double* out_stats,
@@ -609,16 +615,20 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   int cfg;
   if (Cn > 64) cfg = a.rows_per_phase >= 256L * 128 ? 3 : (a.rows_per_phase > 64 ? 0 : 2);
   else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
+  const bool glds_ok = a.bn_in.mode == 0 && Ck % 64 == 0;
+  static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");   // (A/B switch for the static heuristic)
+  if (glds_ok && glds_default) cfg = cfg == 0 ? 5 : (cfg == 3 ? 7 : (cfg == 4 ? 9 : cfg));
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 4) { set_error("bf16 conv plan: tile %d (0..4)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile >= BF16_NTILES) { set_error("bf16 conv plan: tile %d (0..%d)", plan->tile, BF16_NTILES - 1); return MOPOE_ERR_ARG; }
+    if (plan->tile >= 5 && !glds_ok) { set_error("bf16 conv plan: tile %d (LDS-DMA family) needs an operand without BN on load and K channels %% 64 == 0 (Ck = %d)", plan->tile, Ck); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
   }
-  static const int TILE_BM[5] = {128, 256, 64, 256, 128};
-  static const int TILE_BN[5] = {128, 64, 64, 128, 64};
+  static const int TILE_BM[BF16_NTILES] = {128, 256, 64, 256, 128, 128, 128, 256, 256, 128, 128, 256};
+  static const int TILE_BN[BF16_NTILES] = {128, 64, 64, 128, 64, 128, 128, 128, 128, 64, 64, 64};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
-  const int nkc = Ck / BKH;
+  const int nkc = Ck / (cfg >= 5 ? 64 : BKH);    // K chunks per tap (the LDS-DMA tiles walk K 64 deep)
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
   const size_t per = (size_t)a.rows_total * Cn * sizeof(float);
@@ -642,15 +652,35 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
     a.counters = (int*)ws;
     a.partial = (float*)((char*)ws + WS_COUNTER_BYTES);
   }
-  const long persist = cfg == 3 ? PERSIST_BLOCKS_BF16 : PERSIST_BLOCKS_BF16 * 3 / 2;   // 4-wave blocks: 3 per CU share
+  // resident blocks: 8-wave tiles 2 per CU, 4-wave register-staged tiles 3 per CU; the LDS-DMA tiles by their LDS footprint
+  // (64 KB -> 2 per CU, 48 KB -> 3 per CU, 96 KB and more -> 1 per CU)
+  static const int GLDS_PER_CU[BF16_NTILES] = {0, 0, 0, 0, 0, 2, 1, 1, 1, 3, 2, 1};
+  const long persist = cfg >= 5 ? 256L * GLDS_PER_CU[cfg] : (cfg == 3 ? PERSIST_BLOCKS_BF16 : PERSIST_BLOCKS_BF16 * 3 / 2);
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   const double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
   const double flops = 2.0 * (double)g->N * a.Hy * a.Wy * (double)Cn * (double)Ck * taps_eff;
   {
     const int spec = w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1);
     const double abytes = (double)xb + (double)a.rows_total * Cn * (out_f32 ? 4.0 : 2.0);
-    ProfScope prof(stream, flops, PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
+    ProfScope prof(stream, flops, cfg >= 5 ? PROF_BF16_GLDS + (cfg - 5) * 2 + (spec == 3 ? 1 : 0) : PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
+#define MOPOE_LAUNCH_G(BM_, BN_, WM_, WN_, ST_)                                                                                           \
+  do {                                                                                                                                  \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
+    else hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
+  } while (0)
+    if (cfg >= 5) {
+      if (cfg == 5) MOPOE_LAUNCH_G(128, 128, 2, 2, 2);
+      else if (cfg == 6) MOPOE_LAUNCH_G(128, 128, 2, 2, 3);
+      else if (cfg == 7) MOPOE_LAUNCH_G(256, 128, 4, 2, 2);
+      else if (cfg == 8) MOPOE_LAUNCH_G(256, 128, 4, 2, 3);
+      else if (cfg == 9) MOPOE_LAUNCH_G(128, 64, 4, 1, 2);
+      else if (cfg == 10) MOPOE_LAUNCH_G(128, 64, 4, 1, 3);
+      else MOPOE_LAUNCH_G(256, 64, 4, 2, 3);
+      if (int rc = check_launch("gather_gemm_bf16_glds")) return rc;
+      return MOPOE_OK;
+    }
+#undef MOPOE_LAUNCH_G
 #define MOPOE_LAUNCH_H(BM_, BN_, WM_, WN_)                                                                                          \
   do {                                                                                                                            \
     if (spec == 1) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, stream, a);      \

@@ -32,12 +32,46 @@ __device__ __forceinline__ const float* mask_row(const mopoe_mask_ref& mask, lon
   return nullptr;
 }
 
+// Per-channel BatchNorm coefficients, computed ONCE per block into LDS (each needs an fp64 division and square root, ~100
+// instructions; per thread and channel that was up to 16 of them -- 3 us of a 10-us launch in the bf16 family).
+// cf[0..5][c] = mean, rstd, scale (gamma * rstd), shift, k1 = sum0 / count, k2 = sum1 / count  (k1, k2 only with `sums`).
+constexpr int EW_COEF_C = 640;   // channel counts beyond this take the per-thread path (no BASELINE shape does)
+__device__ __forceinline__ void coef_one(const mopoe_bn_ref& bn, const double* sums, int c, int C, float (&o)[6]) {
+  const BnC k = bn_coef(bn, c);
+  o[0] = k.mean; o[1] = k.rstd; o[2] = k.scale; o[3] = k.shift; o[4] = o[5] = 0.f;
+  if (sums && bn.mode == 1) { o[4] = (float)(sums[c] * bn.inv_count); o[5] = (float)(sums[C + c] * bn.inv_count); }
+}
+template <int NF>
+__device__ __forceinline__ void coef_table(const mopoe_bn_ref& bn, const double* sums, int C, float (*cf)[EW_COEF_C]) {
+  if (C > EW_COEF_C) return;
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    float o[6];
+    coef_one(bn, sums, c, C, o);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cf[f][c] = o[f];
+  }
+  __syncthreads();
+}
+// this thread's coefficients of channel c: from the table, or computed here when the table was not built
+template <int NF>
+__device__ __forceinline__ void coef_get(const mopoe_bn_ref& bn, const double* sums, int c, int C,
+                                         const float (*cf)[EW_COEF_C], float (&o)[6]) {
+  if (C <= EW_COEF_C) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) o[f] = f < NF ? cf[f][c] : 0.f;
+  } else {
+    coef_one(bn, sums, c, C, o);
+  }
+}
+
 // ---- out = a*bn(s) + b*m  (+ stats of out) -----------------------------------------------------------
 template <typename T, int VEC, int U>
 __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* __restrict__ s, const T* __restrict__ m,
                                                                  T* __restrict__ out, long rows, int C, mopoe_bn_ref bn,
                                                                  float a, float b, double* stats) {
   const ColLayout L(C, VEC);
+  __shared__ float cf[4][EW_COEF_C];
+  coef_table<4>(bn, nullptr, C, cf);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
     const bool active = cv < L.Cv && L.tr < L.rpp;
@@ -45,7 +79,7 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* __re
     for (int e = 0; e < VEC; ++e) {
       sc[e] = sh[e] = 0.f; part[0][e] = part[1][e] = 0.f;
       const int c = cv * VEC + e;
-      if (active && c < C) { const BnC k = bn_coef(bn, c); sc[e] = a * k.scale; sh[e] = a * k.shift; }
+      if (active && c < C) { float k[6]; coef_get<4>(bn, nullptr, c, C, cf, k); sc[e] = a * k[2]; sh[e] = a * k[3]; }
     }
     if (active) {
       const long step = (long)gridDim.x * L.rpp * U;
@@ -85,6 +119,8 @@ template <typename T, int VEC, int U>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ s, long rows,
                                                                  int C, mopoe_bn_ref bn, double* sums) {
   const ColLayout L(C, VEC);
+  __shared__ float cf[2][EW_COEF_C];
+  coef_table<2>(bn, nullptr, C, cf);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
     const bool active = cv < L.Cv && L.tr < L.rpp;
@@ -92,7 +128,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* __re
     for (int e = 0; e < VEC; ++e) {
       mean[e] = rstd[e] = 0.f; part[0][e] = part[1][e] = 0.f;
       const int c = cv * VEC + e;
-      if (active && c < C) { const BnC k = bn_coef(bn, c); mean[e] = k.mean; rstd[e] = k.rstd; }
+      if (active && c < C) { float k[6]; coef_get<2>(bn, nullptr, c, C, cf, k); mean[e] = k[0]; rstd[e] = k[1]; }
     }
     if (active) {
       const long step = (long)gridDim.x * L.rpp * U;
@@ -129,6 +165,8 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* __re
                                                                  float a, float b, float* dgamma, float* dbeta,
                                                                  float* colsum_dm, float* colsum_ds) {
   const ColLayout L(C, VEC);
+  __shared__ float cf[6][EW_COEF_C];
+  coef_table<6>(bn, sums, C, cf);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
     const bool active = cv < L.Cv && L.tr < L.rpp;
@@ -137,9 +175,10 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_bwd_kernel(const T* __re
       mean[e] = rstd[e] = gr[e] = k1[e] = k2[e] = 0.f; part[0][e] = part[1][e] = 0.f;
       const int c = cv * VEC + e;
       if (active && c < C) {
-        const BnC k = bn_coef(bn, c);
-        mean[e] = k.mean; rstd[e] = k.rstd; gr[e] = a * k.scale;  // a * gamma * rstd
-        if (bn.mode == 1) { k1[e] = (float)(sums[c] * bn.inv_count); k2[e] = (float)(sums[C + c] * bn.inv_count); }
+        float k[6];
+        coef_get<6>(bn, sums, c, C, cf, k);
+        mean[e] = k[0]; rstd[e] = k[1]; gr[e] = a * k[2];  // a * gamma * rstd
+        k1[e] = k[4]; k2[e] = k[5];
         if (blockIdx.x == 0 && L.tr == 0) {
           dgamma[c] = a * (float)sums[C + c];
           dbeta[c] = a * (float)sums[c];
@@ -201,6 +240,10 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
                                                                 mopoe_bn_ref next_bn, double* next_sums) {
   constexpr int NACC = NEXT ? 3 : 1;
   const ColLayout L(C, VEC);
+  __shared__ float cf[6][EW_COEF_C];
+  __shared__ float cfn[NEXT ? 2 : 1][NEXT ? EW_COEF_C : 1];
+  coef_table<6>(bn, sums, C, cf);
+  if constexpr (NEXT) coef_table<2>(next_bn, nullptr, C, cfn);
   for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
     const int cv = cbase + L.tc;
     const bool active = cv < L.Cv && L.tr < L.rpp;
@@ -210,10 +253,10 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
       for (int k = 0; k < NACC; ++k) part[k][e] = 0.f;
       const int c = cv * VEC + e;
       if (active && c < C) {
-        const BnC k = bn_coef(bn, c);
-        mean[e] = k.mean; rstd[e] = k.rstd; gr[e] = k.scale;
-        if (bn.mode == 1) { k1[e] = (float)(sums[c] * bn.inv_count); k2[e] = (float)(sums[C + c] * bn.inv_count); }
-        if (NEXT) { const BnC kn = bn_coef(next_bn, c); nmean[e] = kn.mean; nrstd[e] = kn.rstd; }
+        float k[6];
+        coef_get<6>(bn, sums, c, C, cf, k);
+        mean[e] = k[0]; rstd[e] = k[1]; gr[e] = k[2]; k1[e] = k[4]; k2[e] = k[5];
+        if constexpr (NEXT) { float kn[6]; coef_get<2>(next_bn, nullptr, c, C, cfn, kn); nmean[e] = kn[0]; nrstd[e] = kn[1]; }
         if (blockIdx.x == 0 && L.tr == 0) {
           dgamma[c] = (float)sums[C + c];
           dbeta[c] = (float)sums[c];

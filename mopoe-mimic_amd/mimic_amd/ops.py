@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -417,14 +417,19 @@ def _tuned_plan(key, cands_fn, launch):
 
 
 BF16 = torch.bfloat16
-_GATHER_TILES_BF16 = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64))
+_GATHER_TILES_BF16 = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64),
+                      # 5..11: the LDS-DMA family (csrc/conv_gemm_bf16_glds.inc): operands without a transform on load, K % 64 == 0
+                      (128, 128), (128, 128), (256, 128), (256, 128), (128, 64), (128, 64), (256, 64))
+_GLDS_TILES = {5: 512, 6: 256, 7: 256, 9: 768, 10: 512}     # tile -> blocks resident at once (8 and 11 spill: not offered)
+BF16_GLDS = os.environ.get("MOPOE_BF16_GLDS", "1") != "0"      # A/B switch: keep the tuner on the register-staged tiles
 
 
 def _is16(t):
     return t is not None and t.dtype == BF16
 
 
-def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int):
+def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = False):
+    """plain_operand: the gathered operand enters the MFMA as it lies in memory (no BN -> ReLU on load): the LDS-DMA tiles apply"""
     ws_bytes -= WS_COUNTER_BYTES
     rows, nphase, taps, ck, cn = _gather_shape(kind, g)
     iters = taps * (ck // 32)
@@ -434,7 +439,11 @@ def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int):
         blocks = -(-rows // bm) * -(-cn // bn) * nphase
         if bm == 256 and rows < 256:
             continue
-        cap = 512 if tile == 3 else 768
+        if tile >= 5 and not (BF16_GLDS and plain_operand and ck % 64 == 0 and tile in _GLDS_TILES):
+            continue
+        if tile >= 5 and taps * (ck // 64) < 2:
+            continue     # a single 64-deep chunk per tile: nothing to pipeline
+        cap = _GLDS_TILES[tile] if tile >= 5 else (512 if tile == 3 else 768)
         cands[(tile, 1)] = min(1.0, blocks / cap)
         for sp in _SPLITS:
             if sp * 2 <= iters and blocks * sp <= 2048 and sp * per <= ws_bytes:
@@ -493,7 +502,7 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
                       C.c_size_t(nbytes), stream))
 
         key = ("fwd16", g, bn_in is not None, mask is not None, out_stats is not None, out_dtype) + (("mix",) if mix is not None else ())
-        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("fwd", g, nbytes),
+        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("fwd", g, nbytes, plain_operand=bn_in is None),
                            lambda ref: launch16(ref, _scratch_like(out_stats)))
         launch16(plan, out_stats)
         return y
@@ -541,7 +550,7 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
                       stream))
 
         key = ("dgrad16", g, relu_bn is not None, bwd_sums is not None, out_dtype)
-        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("dgrad", g, nbytes),
+        plan = _tuned_plan(key, lambda: _gather_candidates_bf16("dgrad", g, nbytes, plain_operand=True),
                            lambda ref: launch16(ref, _scratch_like(bwd_sums)))
         launch16(plan, bwd_sums)
         return dx
@@ -923,7 +932,11 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 80
+    names = [None] * 96
+    for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 128, 2, 2, {}, 3", "256, 128, 4, 2, {}, 2", "256, 128, 4, 2, {}, 3",
+                            "128, 64, 4, 1, {}, 2", "128, 64, 4, 1, {}, 3", "256, 64, 4, 2, {}, 3")):
+        for k, spec in enumerate((1, 3)):
+            names[80 + 2 * i + k] = f"gather_gemm_bf16_glds_kernel<{tt.format(spec)}>"
     for tile, tt in enumerate(("128, 128, 2, 2", "256, 64, 4, 1", "64, 64, 2, 2", "256, 128, 4, 2", "128, 64, 4, 1")):
         for spec in (1, 2, 3):
             names[60 + tile * 3 + spec - 1] = f"gather_gemm_bf16_kernel<{tt}, {spec}>"

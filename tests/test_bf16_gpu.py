@@ -151,6 +151,59 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
                       rtol=3e-4, atol_rel=3e-4)
 
 
+def _glds_case(name, g: Geom):
+    """the ops the LDS-DMA tiles serve (csrc/conv_gemm_bf16_glds.inc): forward convs whose operand needs no BN on load
+    (plain, fp32 result, bias + element mask, bias + statistics = a projection shortcut) and every form of the input gradient"""
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(g.in_shape, generator=gen).to(BF)
+    wp = (torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)).to(BF)
+    bias = 0.1 * torch.randn(g.Cout, generator=gen)
+    rows_in = x.numel() // g.Cin
+    rps_out = math.prod(g.out_shape[:3]) // g.N
+    xd, wd = x.to(DEV), wp.to(DEV)
+    if g.Cin % 64 == 0:
+        check16(f"{name}/fwd", ops.conv_fwd(xd, wd, g), TB.conv_fwd(x, wp, g))
+        check16(f"{name}/fwd_f32out", ops.conv_fwd(xd, wd, g, out_dtype=torch.float32), TB.conv_fwd(x, wp, g, out_dtype=torch.float32))
+        emask = Mask((torch.rand(g.out_shape, generator=gen) < 0.5).float() * 2, 2, rps_out)
+        check16(f"{name}/fwd_emask", ops.conv_fwd(xd, wd, g, bias=bias.to(DEV), mask=to_dev(emask)),
+                TB.conv_fwd(x, wp, g, bias=bias, mask=emask))
+        st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+        check16(f"{name}/fwd_shortcut", ops.conv_fwd(xd, wd, g, bias=bias.to(DEV), out_stats=st),
+                TB.conv_fwd(x, wp, g, bias=bias, out_stats=st_ref))
+        check(f"{name}/fwd_shortcut/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
+    if g.Cout % 64 == 0:
+        dy = torch.randn(g.out_shape, generator=gen).to(BF)
+        dyd = dy.to(DEV)
+        check16(f"{name}/dgrad", ops.conv_dgrad(dyd, wd, g), TB.conv_dgrad(dy, wp, g))
+        check16(f"{name}/dgrad_f32out", ops.conv_dgrad(dyd, wd, g, out_dtype=torch.float32), TB.conv_dgrad(dy, wp, g, out_dtype=torch.float32))
+        for mode in (1, 2):
+            bn = make_bn(g.Cin, rows_in, mode, gen, x.float() if mode == 1 else None)
+            s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
+            dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
+            s = torch.zeros(2, g.Cin, dtype=torch.float64, device=DEV)
+            dx = ops.conv_dgrad(dyd, wd, g, relu_bn=to_dev(bn), xin=xd, bwd_sums=s)
+            check16(f"{name}/dgrad_relubn{mode}", dx, dx_ref)
+            check(f"{name}/dgrad_relubn{mode}/sums", s, s_ref, rtol=2e-3, atol_rel=2e-3)
+
+
+GLDS_GEOMS = [GEOMS16[i] for i in (0, 1, 2, 3, 4, 7, 9, 12, 13)] + [
+    ("enc_k4s2p1_64to128_b9_ragged", Geom(9, 8, 8, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1, False)),   # several M tiles, a partial last one
+    ("dec_k4s2p1_64to64_b5", Geom(5, 16, 16, 32, 32, 64, 64, 4, 4, 2, 2, 1, 1, True)),
+    ("odd_grid_k4s2p1_64to192", Geom(3, 6, 5, 12, 10, 64, 192, 4, 4, 2, 2, 1, 1, False)),
+]
+
+
+@pytest.mark.parametrize("name,g", GLDS_GEOMS, ids=[n for n, _ in GLDS_GEOMS])
+def test_conv_lds_dma_tiles_bf16(name, g: Geom):
+    """every LDS-DMA tile (two and three LDS buffers; 128x128, 256x128, 128x64) with and without a split reduction against
+    the emulation, and against the register-staged kernel's result bit for bit where the summation order is the same"""
+    for tile in (5, 6, 7, 9, 10):
+        for split in (1, 2, 3):
+            with ops.force_plan(tile, split):
+                _glds_case(f"{name}/t{tile}s{split}", g)
+
+
 @pytest.mark.parametrize("n,hs,ws", [(2, 16, 16), (3, 5, 16), (2, 6, 6)], ids=["b2_16x16", "b3_5x16_partial_tile", "b2_6x6_streaming"])
 def test_edge_layers_bf16(n, hs, ws):
     """image stem / head with the wide tensor in bf16 (fp32 pixels, taps and tap gradients): MFMA forms (C = 64, rows of

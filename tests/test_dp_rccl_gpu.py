@@ -79,9 +79,15 @@ def test_three_graph_step_over_rccl_matches_eager():
     for kind in ("eager_dp", "graph_dp"):
         for a, b in zip(ref, res[kind]["losses"]):
             assert abs(a - b) <= 2e-4 * abs(a), (kind, ref, res[kind]["losses"])
+        # parameters: within the Adam step bound (5 steps x lr 1e-3; on gradients that are zero up to rounding Adam's
+        # g / sqrt(g^2) turns rounding noise into full-size steps of either sign), most of them far inside it
+        worst = []
         for n, p in res["plain"]["params"].items():
             q = res[kind]["params"][n]
-            assert (p - q).abs().max().item() <= 5e-3 + 1e-3 * p.abs().max().item(), (kind, n)
+            d = (p - q).abs()
+            assert d.max().item() <= 2 * 5 * 1e-3 + 1e-6, (kind, n, d.max().item())
+            worst.append(d.median().item())
+        assert sorted(worst)[len(worst) // 2] <= 1e-4, (kind, sorted(worst)[-5:])
 
 
 def test_bench_starts_its_own_ranks():

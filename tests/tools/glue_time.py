@@ -10,16 +10,25 @@ dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.
 B = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if dt == torch.bfloat16 else 64)
 es = 2 if dt == torch.bfloat16 else 4
 dev = "cuda"
-def t(fn, reps=20):
+def t(fn, reps=10, replays=5):
+    """device time per launch: `reps` launches captured into a hipGraph and replayed (no host cost per launch, which is
+    ~13 us per Python call and hides anything shorter)"""
     for _ in range(3): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): fn()
+    for _ in range(replays): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+    return e0.elapsed_time(e1) / (reps * replays) * 1e3
 print(f"# dtype {dt}, batch {B}, MOPOE_EW_MAX_BLOCKS={os.environ.get('MOPOE_EW_MAX_BLOCKS','-')} MOPOE_EW_ROWS_PER_THREAD={os.environ.get('MOPOE_EW_ROWS_PER_THREAD','-')}")
 tot = 0.0
-for hw, c in ((64 * 64, 64), (32 * 32, 128), (32 * 32, 64), (16 * 16, 192), (16 * 16, 128), (8 * 8, 256), (4 * 4, 320)):
+for hw, c in ((64 * 64, 64), (32 * 32, 128), (32 * 32, 64), (16 * 16, 192), (16 * 16, 128), (8 * 8, 256), (4 * 4, 320),
+              (32, 256), (8, 512), (1, 640)):
     rows = B * hw
     mk = lambda: torch.randn(rows, c, device=dev).to(dt)
     s, m, g, x, add = mk(), mk(), mk(), mk(), mk()
