@@ -380,10 +380,11 @@ template <> struct EwVec<bf16_t> { static constexpr int wide = 8; };
 // rows a thread has in flight per loop iteration (MOPOE_EW_UNROLL = 1 | 2 | 4, read once; tests/tools/glue_time.py sweeps it)
 static inline int ew_unroll() {
   static const int u = ew_env("MOPOE_EW_UNROLL", 4);
-  return u >= 4 ? 4 : (u >= 2 ? 2 : 1);
+  return u >= 8 ? 8 : (u >= 4 ? 4 : (u >= 2 ? 2 : 1));
 }
 #define EW_DISPATCH_U(LAUNCH_)       \
   switch (ew_unroll()) {             \
+    case 8: LAUNCH_(8); break;       \
     case 4: LAUNCH_(4); break;       \
     case 2: LAUNCH_(2); break;       \
     default: LAUNCH_(1); break;      \

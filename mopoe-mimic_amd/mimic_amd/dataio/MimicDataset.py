@@ -26,16 +26,90 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-try:   # the reference tokenises with nltk (MimicDataset.py:14); not every image ships it
-    from nltk.tokenize import word_tokenize
-except ImportError:   # pragma: no cover - depends on the environment
-    _TOKEN = re.compile(r"\d+(?:[.,]\d+)*|\w+(?:[-']\w+)*|[^\w\s]")
+class TokenizerUnavailable(RuntimeError):
+    pass
 
-    def word_tokenize(line: str):
-        """Treebank-like fallback: words (with inner hyphens / apostrophes), numbers, single punctuation marks.  Agrees with
-        nltk on plain clinical prose; contractions and quotes are split differently (a cache written by the reference is
-        read as it is, so this only matters when the vocabulary is built here)."""
-        return _TOKEN.findall(line)
+
+# ---- tokeniser ----------------------------------------------------------------------------------------------------------
+# The reference tokenises with nltk.word_tokenize (MimicDataset.py:14,341-380) = Punkt sentence splitting (a trained model
+# shipped as nltk data) + the Treebank word rules per sentence.  Vocabulary ids are integer work: they are either EXACT or
+# useless to a checkpoint trained on them.  nltk is not part of every image, and its Punkt model cannot be restated, so:
+#   * cache files written by the reference (or by this package where nltk is present) are read as they are -- no
+#     tokenisation happens at all when `mimic.vocab` and `mimic.<split>.s<len>` exist;
+#   * with nltk importable, a missing cache is built with nltk itself;
+#   * without nltk, building a cache is REFUSED (TokenizerUnavailable) unless MOPOE_ALLOW_FALLBACK_TOKENIZER=1: the fallback
+#     below applies the Treebank word rules of nltk 3.8 (restated from its documentation: quotes, final period, ':' ',' not
+#     before digits, '...', ; @ # $ % & ? ! *, brackets, '--', 's 'm 'd 'll 're 've n't, cannot / gonna / wanna ...) and
+#     replaces Punkt by "a period followed by white space ends a sentence unless its token is a listed abbreviation or a
+#     single letter".  It agrees with nltk on the fixtures this repository can check (plain lower-case prose, fixture G6)
+#     and is NOT pinned beyond them ("Text vocabularies").
+try:
+    from nltk.tokenize import word_tokenize as _nltk_word_tokenize
+except ImportError:   # pragma: no cover - depends on the environment
+    _nltk_word_tokenize = None
+
+_STARTING_QUOTES = [(re.compile(r"([\u00ab\u201c\u2018\u201e]|[`]+)"), r" \1 "), (re.compile(r'^"'), r"``"), (re.compile(r"(``)"), r" \1 "),
+                    (re.compile(r"([ \(\[{<])(\"|\'{2})"), r"\1 `` "),
+                    (re.compile(r"(?i)(\')(?!re|ve|ll|m|t|s|d|n)(\w)\b"), r"\1 \2")]
+_PUNCTUATION = [(re.compile(r"([^\.])(\.)([\]\)}>\"\'\u00bb\u201d\u2019 ]*)\s*$"), r"\1 \2 \3 "), (re.compile(r"([:,])([^\d])"), r" \1 \2"),
+                (re.compile(r"([:,])$"), r" \1 "), (re.compile(r"\.{2,}"), r" \g<0> "), (re.compile(r"[;@#$%&]"), r" \g<0> "),
+                (re.compile(r"([^\.])(\.)([\]\)}>\"\']*)\s*$"), r"\1 \2\3 "), (re.compile(r"[?!]"), r" \g<0> "),
+                (re.compile(r"([^'])' "), r"\1 ' "), (re.compile(r"[*]"), r" \g<0> ")]
+_PARENS = (re.compile(r"[\]\[\(\)\{\}\<\>]"), r" \g<0> ")
+_DASHES = (re.compile(r"--"), r" -- ")
+_ENDING_QUOTES = [(re.compile(r"([\u00bb\u201d\u2019])"), r" \1 "), (re.compile(r"''"), " '' "), (re.compile(r'"'), " '' "),
+                  (re.compile(r"([^' ])('[sS]|'[mM]|'[dD]|') "), r"\1 \2 "),
+                  (re.compile(r"([^' ])('ll|'LL|'re|'RE|'ve|'VE|n't|N'T) "), r"\1 \2 ")]
+_CONTRACTIONS = [re.compile(p) for p in (r"(?i)\b(can)(not)\b", r"(?i)\b(d)('ye)\b", r"(?i)\b(gim)(me)\b", r"(?i)\b(gon)(na)\b",
+                                        r"(?i)\b(got)(ta)\b", r"(?i)\b(lem)(me)\b", r"(?i)\b(more)('n)\b", r"(?i)\b(wan)(na)(?=\s)",
+                                        r"(?i) ('t)(is)\b", r"(?i) ('t)(was)\b")]
+_ABBREVIATIONS = {"dr", "mr", "mrs", "ms", "vs", "etc", "e.g", "i.e", "approx", "st", "no", "fig", "inc", "jr", "sr", "prof", "pt"}
+_SENT_END = re.compile(r"(\S+?)([.?!])(\s+)")
+
+
+def _treebank_words(text: str):
+    for rx, sub in _STARTING_QUOTES:
+        text = rx.sub(sub, text)
+    for rx, sub in _PUNCTUATION:
+        text = rx.sub(sub, text)
+    text = _PARENS[0].sub(_PARENS[1], text)
+    text = _DASHES[0].sub(_DASHES[1], text)
+    text = " " + text + " "
+    for rx, sub in _ENDING_QUOTES:
+        text = rx.sub(sub, text)
+    for rx in _CONTRACTIONS:
+        text = rx.sub(r" \1 \2 ", text)
+    return text.split()
+
+
+def _split_sentences(text: str):
+    out, start = [], 0
+    for m in _SENT_END.finditer(text):
+        word = m.group(1).lstrip("([\"'").lower()
+        if m.group(2) == "." and (word in _ABBREVIATIONS or len(word) == 1 or word.replace(",", "").replace(".", "").isdigit()):
+            continue     # "dr. smith", "a. b.", "1. the heart ...": the period stays inside its token, as Punkt keeps it
+        out.append(text[start:m.end(2)])
+        start = m.end()
+    if text[start:].strip():
+        out.append(text[start:])
+    return out
+
+
+def fallback_word_tokenize(line: str):
+    return [tok for sent in _split_sentences(line) for tok in _treebank_words(sent)]
+
+
+def word_tokenize(line: str):
+    if _nltk_word_tokenize is not None:
+        return _nltk_word_tokenize(line)
+    if os.environ.get("MOPOE_ALLOW_FALLBACK_TOKENIZER", "0") != "1":
+        raise TokenizerUnavailable(
+            "building a word vocabulary / sentence cache needs nltk.word_tokenize (the reference's tokeniser, "
+            "mimic/dataio/MimicDataset.py:14): nltk is not importable here.  Use the cache directory the reference wrote "
+            "(oc:<min_occ>_msl:<len>/mimic.vocab + mimic.<split>.s<len>: it is read as it is), install nltk, or set "
+            "MOPOE_ALLOW_FALLBACK_TOKENIZER=1 to accept this package's restatement of the Treebank rules, whose ids are NOT "
+            "guaranteed to match a vocabulary built by the reference")
+    return fallback_word_tokenize(line)
 
 
 class Mimic_testing(Dataset):
@@ -183,73 +257,106 @@ def one_hot_encode(len_seq: int, alphabet: str, seq: str) -> torch.Tensor:
     return x
 
 
-class Mimic(Dataset):
-    """The MIMIC-CXR tensor dataset (reference MimicDataset.py:23-128): same files, label filtering, text encodings and
-    sample contract.  `clf_training` (densenet crops) belongs to the classifiers, which are out of scope."""
+class MimicSplit:
+    """One split of the tensor dataset as arrays, read ONCE: the file reader both dataset forms stand on.
 
-    def __init__(self, args, str_labels, split: str, clf_training=False, transform_images: bool = True):
+    Files (the reference's layout, mimic/dataio/MimicDataset.py:35-44): `<dir_data>/files_small_<img_size>/<split>_{pa,lat}.pt`
+    (uint8 [N, H, W]), `<split>_findings.csv` (column `findings`), `<split>_labels.csv`.  Rows whose labels carry the
+    "uncertain" class -1 are dropped (dataio/utils.filter_labels: the reference's rule, incl. undersampling of the training
+    split).  After construction: `rows` (kept row numbers, int64 [n]), `label_matrix` (float [n, n_labels]), `pa` / `lat`
+    (ALL stored images, indexed by row number), and the text side: a `MimicSentences` (word encoding; sets
+    args.vocab_size) or the alphabet (char encoding; sets args.alphabet / args.num_features)."""
+
+    def __init__(self, args, str_labels, split: str):
         import pandas as pd
-        from .utils import filter_labels, get_transform_img
-        if clf_training:
-            raise NotImplementedError("classifier training transforms are outside the hot path (SURVEY 2.1-13)")
-        self.args, self.split, self.str_labels = args, split, str_labels
-        dir_dataset = os.path.join(args.dir_data, f"files_small_{args.img_size}")
-        self.dir_dataset = dir_dataset
-        self.imgs_pa = torch.load(os.path.join(dir_dataset, split + "_pa.pt"))
-        self.imgs_lat = torch.load(os.path.join(dir_dataset, split + "_lat.pt"))
-        self.report_findings = pd.read_csv(os.path.join(dir_dataset, split + "_findings.csv"))["findings"]
-        labels = pd.read_csv(os.path.join(dir_dataset, split + "_labels.csv"))[str_labels].fillna(0)
-        self.labels = filter_labels(labels, which_labels=str_labels,
-                                    undersample_dataset=getattr(args, "undersample_dataset", False), split=split)
-        self._verify_dataset()
-        if args.text_encoding == "char":
+        from .utils import filter_labels
+        self.args, self.split, self.str_labels = args, split, list(str_labels)
+        self.dir = os.path.join(args.dir_data, f"files_small_{args.img_size}")
+        self.pa = torch.load(os.path.join(self.dir, split + "_pa.pt"))
+        self.lat = torch.load(os.path.join(self.dir, split + "_lat.pt"))
+        self.findings = pd.read_csv(os.path.join(self.dir, split + "_findings.csv"))["findings"]
+        table = pd.read_csv(os.path.join(self.dir, split + "_labels.csv"))[self.str_labels].fillna(0)
+        self.label_frame = filter_labels(table, which_labels=self.str_labels,
+                                         undersample_dataset=getattr(args, "undersample_dataset", False), split=split)
+        self.rows = np.asarray(self.label_frame.index, dtype=np.int64)
+        values = self.label_frame[self.str_labels].values
+        found = np.unique(values)
+        if len(found) != 2:
+            raise AssertionError(f"labels should contain 2 classes, but contains labels {found}. Might need to remove -1 labels")
+        if not (self.pa.shape[0] == self.lat.shape[0] == len(self.findings)):
+            raise AssertionError("all modalities must have the same length")
+        self.label_matrix = torch.from_numpy(values.astype(np.int64)).float()
+        self.sentences = None
+        if args.text_encoding == "word":
+            self.sentences = MimicSentences(max_squence_len=args.len_sequence, data_dir=self.dir, findings=self.findings,
+                                            split=split, transform=True, min_occ=args.word_min_occ)
+            if len(self.sentences) != len(self.findings):
+                raise AssertionError("report findings dataset must have the same length than the report findings dataframe")
+            args.vocab_size = self.sentences.vocab_size
+        elif args.text_encoding == "char":
             from ..utils.utils import get_alphabet
             args.alphabet = get_alphabet(getattr(args, "alphabet_path", None))
             args.num_features = len(args.alphabet)
-            self.get_vec = self.get_char_text_vec
-        elif args.text_encoding == "word":
-            self.report_findings_dataset = self.get_report_findings_dataset(dir_dataset)
-            args.vocab_size = self.report_findings_dataset.vocab_size
-            self.get_vec = self.get_word_text_vec
         else:
             raise NotImplementedError(f"{args.text_encoding} has to be either char or word")
+
+    def __len__(self):
+        return int(self.rows.shape[0])
+
+    def text(self, row: int) -> torch.Tensor:
+        """the text modality of stored row `row`: float token ids [L] (word) or one-hot characters [L, alphabet] (char)"""
+        if self.sentences is not None:
+            return self.sentences[row]
+        report = self.findings[row][:self.args.len_sequence]
+        return one_hot_encode(self.args.len_sequence, self.args.alphabet, report.lower())
+
+    def text_ids(self) -> torch.Tensor:
+        """the kept rows' text as class ids: int32 [n, L] token ids (word) / uint8 [n, L] alphabet positions (char)"""
+        if self.sentences is not None:
+            return self.sentences.id_matrix()[torch.from_numpy(self.rows)]
+        return torch.stack([self.text(int(r)).argmax(-1) for r in self.rows]).to(torch.uint8)
+
+
+class Mimic(Dataset):
+    """Per-sample view of a `MimicSplit` with the reference's constructor and sample contract (mimic/dataio/MimicDataset.py:
+    23-128: `Mimic(args, str_labels, split)`, `ds[i] -> ({'PA', 'Lateral', 'text'}, label)` or None for an unreadable row),
+    for the DataLoader path and for code written against the reference's attributes (`labels`, `imgs_pa`, `imgs_lat`,
+    `report_findings`, `report_findings_dataset`, `transform_img`).  On a GPU the train loop does not iterate this class: it
+    hands `files` to DeviceResidentMimic.  `clf_training` (densenet crops) belongs to the classifiers, out of scope."""
+
+    def __init__(self, args, str_labels, split: str, clf_training=False, transform_images: bool = True):
+        from .utils import get_transform_img
+        if clf_training:
+            raise NotImplementedError("classifier training transforms are outside the hot path (SURVEY 2.1-13)")
+        self.files = MimicSplit(args, str_labels, split)
+        self.args, self.split, self.str_labels = args, split, str_labels
         self.transform_img = get_transform_img(args, getattr(args, "feature_extractor_img", "resnet")) if transform_images \
             else (lambda x: x)
 
-    def __getitem__(self, label_index):
-        try:
-            row = self.labels.iloc[label_index]
-            label = torch.from_numpy((row[self.str_labels].values).astype(int)).float()
-            index = row.name
-            sample = {"PA": self.transform_img(self.imgs_pa[index, :, :]),
-                      "Lateral": self.transform_img(self.imgs_lat[index, :, :]), "text": self.get_vec(index)}
-        except (IndexError, OSError):
-            return None
-        return sample, label
-
-    def get_char_text_vec(self, index):
-        text_str = self.report_findings[index][:self.args.len_sequence]
-        return one_hot_encode(self.args.len_sequence, self.args.alphabet, text_str.lower())
-
-    def get_word_text_vec(self, index):
-        return self.report_findings_dataset[index]
+    # the reference's attribute names
+    labels = property(lambda self: self.files.label_frame)
+    imgs_pa = property(lambda self: self.files.pa)
+    imgs_lat = property(lambda self: self.files.lat)
+    report_findings = property(lambda self: self.files.findings)
+    report_findings_dataset = property(lambda self: self.files.sentences)
+    dir_dataset = property(lambda self: self.files.dir)
 
     def __len__(self):
-        return self.labels.shape[0]
+        return len(self.files)
 
-    def get_report_findings_dataset(self, dir_dataset):
-        ds = MimicSentences(max_squence_len=self.args.len_sequence, data_dir=dir_dataset, findings=self.report_findings,
-                            split=self.split, transform=True, min_occ=self.args.word_min_occ)
-        assert len(ds) == len(self.report_findings), \
-            "report findings dataset must have the same length than the report findings dataframe"
-        return ds
+    def __getitem__(self, i):
+        f = self.files
+        try:
+            row = int(f.rows[i])
+            sample = {"PA": self.transform_img(f.pa[row]), "Lateral": self.transform_img(f.lat[row]), "text": f.text(row)}
+            return sample, f.label_matrix[i].clone()
+        except (IndexError, OSError):
+            return None
 
-    def _verify_dataset(self):
-        labels = self.labels.values
-        assert len(np.unique(labels)) == 2, \
-            f"labels should contain 2 classes, but contains labels {np.unique(labels)}. Might need to remove -1 labels"
-        assert self.imgs_pa.shape[0] == self.imgs_lat.shape[0] == len(self.report_findings), \
-            "all modalities must have the same length"
+    def get_char_text_vec(self, row):
+        return self.files.text(row)
+
+    get_word_text_vec = get_char_text_vec
 
 
 class DeviceResidentMimic:
@@ -264,24 +371,23 @@ class DeviceResidentMimic:
     wrap-around to a multiple of world_size, rank r takes elements r, r + W, ...; `drop_last` is False like the
     reference's DataLoader (the last batch may be short: the train loop runs it eagerly)."""
 
-    def __init__(self, dataset: Mimic, device, batch_size: int, shuffle: bool = True, rank: int = 0, world_size: int = 1,
+    def __init__(self, dataset, device, batch_size: int, shuffle: bool = True, rank: int = 0, world_size: int = 1,
                  seed: int = 0):
+        """dataset: a MimicSplit, or a Mimic (its `files`)"""
         from .utils import resize_u8
+        files = dataset.files if isinstance(dataset, Mimic) else dataset
+        args = dataset.args if isinstance(dataset, Mimic) else files.args      # (a view may ask for another image size)
         self.device, self.batch_size, self.shuffle = torch.device(device), int(batch_size), shuffle
         self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
-        idx = torch.as_tensor(np.asarray(dataset.labels.index), dtype=torch.long)
-        size = int(dataset.args.img_size)
-        self.pa = resize_u8(dataset.imgs_pa[idx], size).to(self.device)        # [n, S, S] uint8
-        self.lat = resize_u8(dataset.imgs_lat[idx], size).to(self.device)
-        if dataset.args.text_encoding == "word":
-            self.text = dataset.report_findings_dataset.id_matrix()[idx].to(self.device)   # [n, L] int32
-            self.num_features = None
-        else:   # char: class ids [n, L] (uint8), expanded to one-hot rows on the device
-            self.num_features = len(dataset.args.alphabet)
-            ids = torch.stack([dataset.get_char_text_vec(int(i)).argmax(-1) for i in idx])
-            self.text = ids.to(torch.uint8).to(self.device)
-        self.labels = torch.from_numpy(dataset.labels[dataset.str_labels].values.astype(np.int64)).float().to(self.device)
-        self.n = int(idx.numel())
+        idx = torch.from_numpy(files.rows)
+        size = int(args.img_size)
+        self.pa = resize_u8(files.pa[idx], size).to(self.device)        # [n, S, S] uint8
+        self.lat = resize_u8(files.lat[idx], size).to(self.device)
+        # word: token ids [n, L] int32; char: alphabet positions [n, L] uint8, expanded to one-hot rows on the device
+        self.num_features = None if files.sentences is not None else len(files.args.alphabet)
+        self.text = files.text_ids().to(self.device)
+        self.labels = files.label_matrix.to(self.device)
+        self.n = len(files)
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch

@@ -14,6 +14,10 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # the hundreds of geometries the suite touches.  Tests run on the library's static heuristic unless they opt in
 # (`tuned_plans` fixture); every plan the tuner can pick is forced and checked in test_conv_every_launch_plan.
 os.environ.setdefault("MOPOE_AUTOTUNE", "0")
+# nltk is not in this image: the dataset tests build their vocabularies with the package's restatement of the Treebank
+# rules (dataio/MimicDataset.py, refused by default).  Fixture G6's reports are plain lower-case words, on which every
+# tokeniser agrees -- that is what the fixture pins; test_tokenizer_policy covers the refusal and the rule set.
+os.environ.setdefault("MOPOE_ALLOW_FALLBACK_TOKENIZER", "1")
 
 
 def pytest_configure(config):

@@ -312,10 +312,20 @@ def _model_vs_oracle(cfg, nrow, seed, tag, mode="train_nodrop", grad_check=True)
         masks = ctx0.masks
     leaf = R.leaf_state(sd)
     ref16 = R.forward_step(cfg, leaf, batch, eps, R.Ctx(mode, masks=masks, bf16=True))
+    g16 = g32 = None
     if grad_check:
         ref16["total_loss"].backward()
-    with torch.no_grad():
-        ref32 = R.forward_step(cfg, sd, batch, eps, R.Ctx(mode, masks=masks))
+        g16 = {k: v.grad.clone() for k, v in leaf.items() if v.is_floating_point() and v.grad is not None}
+        ref16 = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ref16.items()}     # (drop the autograd graph)
+        for v in leaf.values():
+            v.grad = None
+        # the reference (fp32) arithmetic's gradients too: how far bf16 rounding ITSELF moves each gradient is the yardstick
+        ref32 = R.forward_step(cfg, leaf, batch, eps, R.Ctx(mode, masks=masks))
+        ref32["total_loss"].backward()
+        g32 = {k: v.grad.clone() for k, v in leaf.items() if v.is_floating_point() and v.grad is not None}
+    else:
+        with torch.no_grad():
+            ref32 = R.forward_step(cfg, sd, batch, eps, R.Ctx(mode, masks=masks))
     exp = build_exp(cfg, sd, "cuda", mode, masks=masks, eps=eps, compute_dtype="bf16")
     got = RE.basic_routine_epoch(exp, ({k: v.cuda() for k, v in batch.items()}, None))
     rows = []
@@ -340,28 +350,49 @@ def _model_vs_oracle(cfg, nrow, seed, tag, mode="train_nodrop", grad_check=True)
     exp.mm_vae.zero_grad()
     got["total_loss"].backward()
     grads = exp.mm_vae.reference_named_grads()
-    g16 = {k: v.grad for k, v in leaf.items() if v.is_floating_point() and v.grad is not None}
     assert set(grads) == set(g16)
-    bad, cos_all = [], []
+    # Gates derived from the logged distributions (gpurun_out/bf16_parity.log; round 3, C3 at B = 256: tensors whose gradient
+    # norm is above the bf16 noise floor: median rel-L2 2.5e-2, p90 7.2e-2, max 1.2e-1 -- the decoders' bn1 / conv1, the
+    # deepest points of the backward chain; C3 at B = 16: median 3.0e-2, p90 9.1e-2, max 1.5e-1).  Two bf16 implementations
+    # that round at the same points but sum in different orders differ by about the noise bf16 itself adds, so the second
+    # yardstick is the FP32 reference gradient: the HIP gradient must be as close to it as the bf16-mode oracle's is.
+    #   regular tensor:   rel-L2 vs the bf16-mode oracle <= 0.15 (full size) / 0.2 (B <= 16), cosine >= 0.985;
+    #                     rel-L2 vs the fp32 oracle <= 1.5 x the bf16-mode oracle's own + 2e-2;
+    #                     over all regular tensors: median <= 4e-2, 90th percentile <= 0.11
+    #   analytically zero gradients (a bias in front of a BatchNorm, the shortcut BatchNorm's bias in front of the next
+    #   block's BatchNorm: both sides hold pure rounding noise): |error| <= half the bf16 noise floor of the tensor
+    # A gradient that is wrong by 20 % in one tensor fails the first line.
+    full = nrow >= 32        # BASELINE configs at full size; the small / B <= 16 runs average over fewer rows per gradient
+    cap, cos_min, med_max, p90_max = (0.15, 0.985, 4e-2, 0.11) if full else (0.22, 0.975, 6e-2, 0.15)
+    bad, cos_all, rel_reg = [], [], []
     for name, gr in grads.items():
-        a, b = gr.double().cpu().flatten(), g16[name].double().flatten()
+        a, b, c = gr.double().cpu().flatten(), g16[name].double().flatten(), g32[name].double().flatten()
         assert torch.isfinite(a).all(), name
         scale = max(b.abs().max().item(), 1e-3)
         if name.endswith(".bias") and name[:-4] + "weight" in g16:
             scale = max(scale, g16[name[:-4] + "weight"].abs().max().item())
         floor = 2e-2 * scale * a.numel() ** 0.5          # bf16 noise floor for (near-)zero gradients
+        below = b.norm().item() <= floor
         rel_l2 = ((a - b).norm() / max(b.norm().item(), floor)).item()
-        cos = (torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)).item() if b.norm().item() > floor else 1.0
-        cos_all.append(cos)
-        _log(f"{tag} grad {name}: relL2={rel_l2:.3e} cos={cos:.5f} scale={scale:.3e}")
-        # bulk bound per tensor.  The worst tensors are the decoders' bn1 biases (sums of sign-alternating gradient rows:
-        # the same tensors are the worst ones of the fp32 path too, at 3e-3 where the median is 3e-5 -- two orders of
-        # cancellation, which bf16's 2^-9 per element turns into 0.13-0.16; measured, gpurun_out/bf16_parity.log)
-        if not (rel_l2 <= 0.3 and cos >= 0.97):
-            bad.append((name, rel_l2, cos))
-    _log(f"{tag} grads: median cos={np.median(cos_all):.6f} min cos={min(cos_all):.5f} n={len(cos_all)}")
+        cos = 1.0 if below else (torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+        e_hip32 = ((a - c).norm() / max(c.norm().item(), floor)).item()
+        e_ref32 = ((b - c).norm() / max(c.norm().item(), floor)).item()
+        _log(f"{tag} grad {name}: relL2={rel_l2:.3e} cos={cos:.5f} scale={scale:.3e} vs_fp32: hip={e_hip32:.3e} oracle_bf16={e_ref32:.3e}"
+             + (" (below the noise floor)" if below else ""))
+        if below:
+            ok = rel_l2 <= 0.5
+        else:
+            cos_all.append(cos)
+            rel_reg.append(rel_l2)
+            ok = rel_l2 <= cap and cos >= cos_min and e_hip32 <= 1.5 * e_ref32 + 2e-2
+        if not ok:
+            bad.append((name, round(rel_l2, 4), round(cos, 5), round(e_hip32, 4), round(e_ref32, 4), below))
+    q = np.quantile(rel_reg, [0.5, 0.9])
+    _log(f"{tag} grads: {len(rel_reg)} regular tensors: rel-L2 median={q[0]:.3e} p90={q[1]:.3e} max={max(rel_reg):.3e}; "
+         f"median cos={np.median(cos_all):.6f} min cos={min(cos_all):.5f}")
     assert not bad, bad[:10]
-    assert np.median(cos_all) >= 0.998, np.median(cos_all)   # (measured: 0.9989 with dropout at B = 8 ... 0.9996 at C3 shapes)
+    assert q[0] <= med_max and q[1] <= p90_max, q
+    assert np.median(cos_all) >= 0.998, np.median(cos_all)   # (measured: 0.9989 with dropout at B = 8 ... 0.9997 at C3, B = 256)
     return exp
 
 
@@ -381,17 +412,68 @@ def test_c3_shape_bf16_vs_oracle_b16():
 
 def test_c3_full_size_bf16():
     """BASELINE config #3 exactly: 128 px, class_dim 128, B = 256, bf16 -- forward scalars against the oracle (bf16 mode
-    and fp32 arithmetic), then three Adam steps (finite gradients, decreasing loss)."""
+    and fp32 arithmetic), EVERY parameter gradient against the bf16-mode oracle's backward (one CPU backward at B = 256),
+    then three Adam steps (finite gradients, decreasing loss)."""
     cfg = R.Cfg(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=256)
-    exp = _model_vs_oracle(cfg, 256, seed=91, tag="c3_b256", grad_check=False)
+    exp = _model_vs_oracle(cfg, 256, seed=91, tag="c3_b256", grad_check=True)
     _three_steps(exp, cfg, 256, seed=92)
 
 
 def test_c5_full_size_bf16():
-    """BASELINE config #5 exactly: 256 px (the stride-4 block), class_dim 256, B = 32, bf16."""
+    """BASELINE config #5 exactly: 256 px (the stride-4 block), class_dim 256, B = 32, bf16: forward scalars and every
+    parameter gradient."""
     cfg = R.Cfg(img_size=256, class_dim=256, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=32)
-    exp = _model_vs_oracle(cfg, 32, seed=95, tag="c5_b32", grad_check=False)
+    exp = _model_vs_oracle(cfg, 32, seed=95, tag="c5_b32", grad_check=True)
     _three_steps(exp, cfg, 32, seed=96)
+
+
+_TRAJ = {}
+
+
+def _fp32_oracle_trajectory(cfg, nrow, order, lr):
+    """losses of the fp32 CPU oracle over the Adam steps `order` (batch indices), computed once per test session"""
+    key = (cfg.img_size, cfg.class_dim, nrow, tuple(order), lr)
+    if key not in _TRAJ:
+        sd = R.init_state(cfg, seed=61)
+        batches = [R.synthetic_batch(cfg, nrow, seed=600 + i) for i in range(max(order) + 1)]
+        eps = batches[0][1]
+        leaf = R.leaf_state({k: v.clone() for k, v in sd.items()})
+        opt = torch.optim.Adam([v for v in leaf.values() if v.is_floating_point() and v.requires_grad], lr=lr)
+        losses = [R.adam_train_step(cfg, leaf, opt, batches[i][0], eps, R.Ctx("train_nodrop"))["total_loss"].item() for i in order]
+        _TRAJ[key] = (sd, batches, eps, losses)
+    return _TRAJ[key]
+
+
+@pytest.mark.parametrize("form", ["eager", "graph"])
+def test_bf16_trajectory_vs_fp32_oracle(form):
+    """ten Adam steps of the bf16 family at BASELINE config #3's architecture (B = 32) against the FP32 reference arithmetic
+    (oracle/mopoe_ref.py on the CPU), loss by loss at SURVEY 8c's bf16 tolerance (rtol 2e-2): the bf16 rounding points must
+    not bend the optimisation trajectory.  Both step forms: eager train_step and the captured hipGraph."""
+    cfg = R.Cfg(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=32)
+    order, lr = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8], 5e-5
+    sd, batches, eps, ref = _fp32_oracle_trajectory(cfg, 32, order, lr)
+    exp = build_exp(cfg, {k: v.clone() for k, v in sd.items()}, "cuda", "train_nodrop", eps=eps, compute_dtype="bf16")
+    exp.flags.initial_learning_rate = lr
+    exp.set_optimizer(capturable=(form == "graph"))
+    pack = RE.ScalarPack(exp.flags.device)
+    dev = lambda i: ({k: v.cuda() for k, v in batches[i][0].items()}, None)
+    got = []
+    if form == "eager":
+        for i in order:
+            RE.train_step(exp, dev(i), None, pack)
+            got.append(pack.read()["total_loss"])
+    else:
+        step = RE.GraphedTrainStep(exp, dev(0), pack, None, warmup=2)     # (= the first two steps of `order`, eager)
+        got = [None, None]
+        for i in order[2:]:
+            step(dev(i))
+            got.append(pack.read()["total_loss"])
+    for k, (g, r) in enumerate(zip(got, ref)):
+        if g is None:
+            continue
+        _log(f"traj_{form} step {k}: hip_bf16={g:.6g} oracle_fp32={r:.6g} rel={_rel(g, r):.2e}")
+        assert _rel(g, r) <= 2e-2, (form, k, g, r)
+    assert ref[-1] < ref[0]      # (the trajectory moves: the comparison is not of ten copies of one number)
 
 
 def test_c5_full_size_fp32_properties():

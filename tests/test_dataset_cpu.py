@@ -142,3 +142,31 @@ def test_sentences_unknown_words_and_truncation(tmp_path):
                         transform=True, min_occ=4)
     assert ev[0].tolist() == [w2i["b"], w2i["<exc>"], w2i["c"], w2i["<eos>"], w2i["<pad>"]]
     assert ev[1].tolist() == [w2i["c"]] * 4 + [w2i["<eos>"]]           # cut to len - 1 tokens + <eos>
+
+
+def test_tokenizer_policy(monkeypatch):
+    """Vocabulary ids are integer work: without nltk (the reference's tokeniser) a cache is not built silently with something
+    else.  The fallback applies nltk's Treebank word rules; the expected tokens below are what those rules give on paper for
+    the cases VERDICT r2 named (contractions, quotes, '...', decimals / commas in numbers) -- they were NOT generated by
+    nltk (absent here), so they document the restatement, they do not pin it to the reference."""
+    from mimic_amd.dataio import MimicDataset as MD
+    cases = {
+        "no acute cardiopulmonary process. heart size is normal.":
+            ["no", "acute", "cardiopulmonary", "process", ".", "heart", "size", "is", "normal", "."],
+        "the patient's lungs are clear; there's no effusion, 2.5 cm nodule (stable) in the rul.":
+            ["the", "patient", "'s", "lungs", "are", "clear", ";", "there", "'s", "no", "effusion", ",", "2.5", "cm", "nodule", "(",
+             "stable", ")", "in", "the", "rul", "."],
+        'dr. smith said "don\'t worry" ... pa and lateral views, 1,000 ml -- unchanged?':
+            ["dr.", "smith", "said", "``", "do", "n't", "worry", "''", "...", "pa", "and", "lateral", "views", ",", "1,000", "ml", "--",
+             "unchanged", "?"],
+        "cannot exclude pneumonia: follow-up recommended.": ["can", "not", "exclude", "pneumonia", ":", "follow-up", "recommended", "."],
+        "a b c": ["a", "b", "c"],
+    }
+    for line, want in cases.items():
+        assert MD.fallback_word_tokenize(line) == want, line
+    if MD._nltk_word_tokenize is None:
+        monkeypatch.setenv("MOPOE_ALLOW_FALLBACK_TOKENIZER", "0")
+        with pytest.raises(MD.TokenizerUnavailable):
+            MD.word_tokenize("a b c")
+        monkeypatch.setenv("MOPOE_ALLOW_FALLBACK_TOKENIZER", "1")
+        assert MD.word_tokenize("a b c") == ["a", "b", "c"]
