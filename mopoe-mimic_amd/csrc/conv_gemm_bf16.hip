@@ -360,8 +360,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_bf16_kernel(const 
 #include "gemm_colstats_rows.inc"
 }
 
-#include "conv_gemm_bf16_glds.inc"
-
 // =====================================================================================================
 // weight gradient: dWp[tap][ci][co] (fp32) = sum over pixels of T(x)[pixel][ci] * dy[pixel][co]
 // K = pixels is the strided index of BOTH operands: both tiles are staged [pixel][channel] as they lie in memory and
@@ -543,6 +541,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm_bf16_kernel(const WgradArgsH a
   }
 }
 
+#include "conv_gemm_bf16_glds.inc"
+
 // =====================================================================================================
 // host-side launchers
 // =====================================================================================================
@@ -615,12 +615,15 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   int cfg;
   if (Cn > 64) cfg = a.rows_per_phase >= 256L * 128 ? 3 : (a.rows_per_phase > 64 ? 0 : 2);
   else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
-  const bool glds_ok = a.bn_in.mode == 0 && Ck % 64 == 0;
+  const bool glds_ok = Ck % 64 == 0;     // (with BN on load: the two-buffer tiles 5, 7, 9 only)
   static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");   // (A/B switch for the static heuristic)
   if (glds_ok && glds_default) cfg = cfg == 0 ? 5 : (cfg == 3 ? 7 : (cfg == 4 ? 9 : cfg));
   if (plan && plan->tile >= 0) {
     if (plan->tile >= BF16_NTILES) { set_error("bf16 conv plan: tile %d (0..%d)", plan->tile, BF16_NTILES - 1); return MOPOE_ERR_ARG; }
-    if (plan->tile >= 5 && !glds_ok) { set_error("bf16 conv plan: tile %d (LDS-DMA family) needs an operand without BN on load and K channels %% 64 == 0 (Ck = %d)", plan->tile, Ck); return MOPOE_ERR_ARG; }
+    if (plan->tile >= 5 && (!glds_ok || (a.bn_in.mode != 0 && plan->tile != 5 && plan->tile != 7 && plan->tile != 9))) {
+      set_error("bf16 conv plan: tile %d (LDS-DMA family) needs K channels %% 64 == 0 (Ck = %d) and, with BN on load, one of the two-buffer tiles 5, 7, 9", plan->tile, Ck);
+      return MOPOE_ERR_ARG;
+    }
     cfg = plan->tile;
   }
   static const int TILE_BM[BF16_NTILES] = {128, 256, 64, 256, 128, 128, 128, 256, 256, 128, 128, 256};
@@ -662,15 +665,22 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   {
     const int spec = w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1);
     const double abytes = (double)xb + (double)a.rows_total * Cn * (out_f32 ? 4.0 : 2.0);
-    ProfScope prof(stream, flops, cfg >= 5 ? PROF_BF16_GLDS + (cfg - 5) * 2 + (spec == 3 ? 1 : 0) : PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
+    ProfScope prof(stream, flops, cfg >= 5 ? (spec == 2 ? PROF_BF16_GLDS_X + (cfg - 5) / 2 : PROF_BF16_GLDS + (cfg - 5) * 2 + (spec == 3 ? 1 : 0))
+                                           : PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
 #define MOPOE_LAUNCH_G(BM_, BN_, WM_, WN_, ST_)                                                                                           \
   do {                                                                                                                                  \
     if (spec == 1) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
     else hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
   } while (0)
+#define MOPOE_LAUNCH_GX(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 2, 2>), grid, dim3(64 * WM_ * WN_), 0, stream, a)
     if (cfg >= 5) {
-      if (cfg == 5) MOPOE_LAUNCH_G(128, 128, 2, 2, 2);
+      if (spec == 2) {
+        if (cfg == 5) MOPOE_LAUNCH_GX(128, 128, 2, 2);
+        else if (cfg == 7) MOPOE_LAUNCH_GX(256, 128, 4, 2);
+        else MOPOE_LAUNCH_GX(128, 64, 4, 1);
+      }
+      else if (cfg == 5) MOPOE_LAUNCH_G(128, 128, 2, 2, 2);
       else if (cfg == 6) MOPOE_LAUNCH_G(128, 128, 2, 2, 3);
       else if (cfg == 7) MOPOE_LAUNCH_G(256, 128, 4, 2, 2);
       else if (cfg == 8) MOPOE_LAUNCH_G(256, 128, 4, 2, 3);
@@ -762,18 +772,25 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   const bool pow2 = a.lg_ws >= 0 && a.lg_hw >= 0;
   const int taps = g->kh * g->kw;
   bool big = g->Cin > 64 && g->Cout > 64;
-  if (plan && plan->tile == 2) big = false;
+  if (plan && (plan->tile == 2 || plan->tile == 6)) big = false;
+  if (plan && plan->tile == 5) big = true;
+  // plan tiles: 0 = 128x128, 2 = 64x64 (register-staged, 32 pixels per chunk); 5 = 128x128, 6 = 64x64 on LDS-DMA (64 pixels
+  // per stage).  Default: the LDS-DMA form (MOPOE_BF16_NO_GLDS = the register-staged one).
+  static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");
+  const bool glds = plan && plan->tile >= 0 ? plan->tile >= 5 : glds_default;
+  if (plan && plan->tile > 6) { set_error("bf16 wgrad plan: tile %d (0, 2, 5, 6)", plan->tile); return MOPOE_ERR_ARG; }
   const int T = big ? 128 : 64;
   const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
   a.nJ = nJ;
   const long tiles = (long)nI * nJ * taps;
   long split = (1024 + tiles - 1) / tiles;
   if (plan && plan->split > 0) split = plan->split;
-  const long max_split = (a.Ms + 4 * BKH - 1) / (4 * BKH);
+  const int kp = glds ? 64 : BKH;                 // pixels per chunk
+  const long max_split = (a.Ms + 4 * kp - 1) / (4 * kp);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   long chunk = (a.Ms + split - 1) / split;
-  chunk = (chunk + BKH - 1) / BKH * BKH;
+  chunk = (chunk + kp - 1) / kp * kp;
   split = (a.Ms + chunk - 1) / chunk;
   a.chunk = chunk;
   a.atomic = split > 1;
@@ -785,8 +802,21 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   const bool xf = a.bn_in.mode != 0;
-  ProfScope prof(stream, flops, PROF_BF16_WGRAD + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
+  ProfScope prof(stream, flops, (glds ? PROF_BF16_WGRAD_GLDS : PROF_BF16_WGRAD) + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
   dim3 grid(nI * nJ, taps, (unsigned)split);
+  if (glds) {
+#define MOPOE_LAUNCH_WG(T_)                                                                                             \
+  do {                                                                                                                 \
+    if (xf && pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<T_, true, true>), grid, dim3(256), 0, stream, a);      \
+    else if (xf) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<T_, true, false>), grid, dim3(256), 0, stream, a);        \
+    else if (pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<T_, false, true>), grid, dim3(256), 0, stream, a);      \
+    else hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<T_, false, false>), grid, dim3(256), 0, stream, a);               \
+  } while (0)
+    if (big) MOPOE_LAUNCH_WG(128);
+    else MOPOE_LAUNCH_WG(64);
+#undef MOPOE_LAUNCH_WG
+    return check_launch("wgrad_gemm_bf16_glds");
+  }
 #define MOPOE_LAUNCH_WH(T_)                                                                                              \
   do {                                                                                                                 \
     if (xf && pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_kernel<T_, T_, true, true>), grid, dim3(256), 0, stream, a);        \

@@ -117,8 +117,14 @@ static inline int ew_env(const char* name, int dflt) {
   return v && atoi(v) > 0 ? atoi(v) : dflt;
 }
 static inline int ew_grid(long rows, int C, int VEC) {
-  static const int max_blocks = ew_env("MOPOE_EW_MAX_BLOCKS", EW_MAX_BLOCKS);
+  // Block count of a row-streaming kernel.  Every block ends in one atomic per column and accumulator on the SAME addresses,
+  // and same-address atomics serialise at the memory side at ~18 ns each (measured: +9.2 us per 512 additional blocks,
+  // profiles/r03_glue_sweep.txt): a tail of blocks x 18 ns that only the largest tensors amortise.  One block per CU (256,
+  // four rows in flight per thread) streams tensors of up to ~100 MB per stream at the same rate as two per CU; beyond that
+  // the second block per CU is worth more than its share of the tail.
+  static const int max_blocks_env = ew_env("MOPOE_EW_MAX_BLOCKS", 0);
   static const int rows_per_thread = ew_env("MOPOE_EW_ROWS_PER_THREAD", 8);
+  const int max_blocks = max_blocks_env > 0 ? max_blocks_env : ((double)rows * C * (VEC == 8 ? 2.0 : 4.0) > 96e6 ? EW_MAX_BLOCKS : 256);
   const int Cv = (C + VEC - 1) / VEC;
   const int cols = Cv < EW_THREADS ? Cv : EW_THREADS;
   const int rpp = EW_THREADS / cols;

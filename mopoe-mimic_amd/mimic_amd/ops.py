@@ -339,13 +339,14 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
     return cands
 
 
-def _wgrad_candidates(g: Geom):
+def _wgrad_candidates(g: Geom, bf16: bool = False):
     if min(g.Cin, g.Cout) == 1:
         return {}
     ms = g.N * g.Hs * g.Ws
     cands = {}
-    for tile, tsz in ((0, 128), (2, 64)):
-        if tile == 0 and (g.Cin <= 64 or g.Cout <= 64):
+    # bf16: tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_bf16_glds.inc)
+    for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if bf16 and BF16_GLDS else ((0, 128), (2, 64))):
+        if tsz == 128 and (g.Cin <= 64 or g.Cout <= 64):
             continue
         tiles = -(-g.Cin // tsz) * -(-g.Cout // tsz) * g.taps
         seen = set()
@@ -439,8 +440,8 @@ def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int, plain_operand: bo
         blocks = -(-rows // bm) * -(-cn // bn) * nphase
         if bm == 256 and rows < 256:
             continue
-        if tile >= 5 and not (BF16_GLDS and plain_operand and ck % 64 == 0 and tile in _GLDS_TILES):
-            continue
+        if tile >= 5 and not (BF16_GLDS and ck % 64 == 0 and tile in _GLDS_TILES and (plain_operand or tile in (5, 7, 9))):
+            continue     # (with BN -> ReLU on load only the two-buffer tiles exist)
         if tile >= 5 and taps * (ck // 64) < 2:
             continue     # a single 64-deep chunk per tile: nothing to pipeline
         cap = _GLDS_TILES[tile] if tile >= 5 else (512 if tile == 3 else 768)
@@ -598,7 +599,7 @@ def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
     def launch(plan, dst, is_zero):
         _check(fn(_p(x), _p(dy), _p(dst), C.byref(gc), bnr, C.c_int32(is_zero), plan, stream))
 
-    plan = _tuned_plan(key, lambda: _wgrad_candidates(g), lambda ref: launch(ref, _scratch_like(dwp), 1))
+    plan = _tuned_plan(key, lambda: _wgrad_candidates(g, bf16=key[0] == "wgrad16"), lambda ref: launch(ref, _scratch_like(dwp), 1))
     launch(plan, dwp, int(out is not None))
     return dwp
 
@@ -932,7 +933,12 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 96
+    names = [None] * 104
+    for i, tt in enumerate(("128", "64")):
+        for xf in (0, 1):
+            names[100 + 2 * i + xf] = f"wgrad_gemm_bf16_glds_kernel<{tt}, {'true' if xf else 'false'}, true>"
+    for i, tt in enumerate(("128, 128, 2, 2, 2, 2", "256, 128, 4, 2, 2, 2", "128, 64, 4, 1, 2, 2")):
+        names[94 + i] = f"gather_gemm_bf16_glds_kernel<{tt}>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 128, 2, 2, {}, 3", "256, 128, 4, 2, {}, 2", "256, 128, 4, 2, {}, 3",
                             "128, 64, 4, 1, {}, 2", "128, 64, 4, 1, {}, 3", "256, 64, 4, 2, {}, 3")):
         for k, spec in enumerate((1, 3)):

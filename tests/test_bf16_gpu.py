@@ -141,7 +141,7 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
         for split in (1, 2, 3, 8):
             with ops.force_plan(tile, split):
                 _conv_case(f"{name}/t{tile}s{split}", g)
-    for tile in (0, 2):
+    for tile in (0, 2, 5, 6):      # 5 / 6: the 128 / 64 tiles on LDS-DMA (64 pixels per stage)
         for split in (1, 2, 5):
             with ops.force_plan(tile, split):
                 gen = torch.Generator().manual_seed(7)
@@ -149,6 +149,9 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
                 dy = torch.randn(g.out_shape, generator=gen).to(BF)
                 check(f"{name}/wgrad_t{tile}s{split}", ops.conv_wgrad(x.to(DEV), dy.to(DEV), g), TB.conv_wgrad(x, dy, g),
                       rtol=3e-4, atol_rel=3e-4)
+                bn = make_bn(g.Cin, x.numel() // g.Cin, 1, gen, x.float())
+                check(f"{name}/wgrad_bn_t{tile}s{split}", ops.conv_wgrad(x.to(DEV), dy.to(DEV), g, bn_in=to_dev(bn)),
+                      TB.conv_wgrad(x, dy, g, bn_in=bn), rtol=2e-3, atol_rel=1e-3)
 
 
 def _glds_case(name, g: Geom):
@@ -187,6 +190,39 @@ def _glds_case(name, g: Geom):
             check(f"{name}/dgrad_relubn{mode}/sums", s, s_ref, rtol=2e-3, atol_rel=2e-3)
 
 
+def _glds_xform_case(name, g: Geom):
+    """forward convs with BN -> ReLU on the gathered operand on the LDS-DMA tiles (weights by DMA, activations through
+    registers): conv1 / conv2 of a residual block, with and without the residual mix in the epilogue"""
+    if g.Cin % 64:
+        return
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(g.in_shape, generator=gen).to(BF)
+    wp = (torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)).to(BF)
+    bias = 0.1 * torch.randn(g.Cout, generator=gen)
+    rows_in = x.numel() // g.Cin
+    rows_out = math.prod(g.out_shape[:3])
+    rps_out = rows_out // g.N
+    xd, wd = x.to(DEV), wp.to(DEV)
+    for mode in (1, 2):
+        bn = make_bn(g.Cin, rows_in, mode, gen, x.float() if mode == 1 else None)
+        cmask = Mask((torch.rand(g.N, g.Cout, generator=gen) < 0.5).float() * 2, 1, rps_out)
+        st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref)
+        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+        y = ops.conv_fwd(xd, wd, g, bn_in=to_dev(bn), bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st)
+        check16(f"{name}/fwd_fused_bn{mode}", y, y_ref, atol_rel=1.5e-3)
+        check(f"{name}/fwd_fused_bn{mode}/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
+        sres = torch.randn(g.out_shape, generator=gen).to(BF)
+        bns = make_bn(g.Cout, rows_out, mode, gen, sres.float() if mode == 1 else None)
+        st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+        y_ref = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=st_ref, mix=(sres, bns))
+        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+        y = ops.conv_fwd(xd, wd, g, bn_in=to_dev(bn), bias=bias.to(DEV), mask=to_dev(cmask), out_stats=st,
+                         mix=(sres.to(DEV), to_dev(bns)))
+        check16(f"{name}/fwd_mix_bn{mode}", y, y_ref, atol_rel=1.5e-3)
+        check(f"{name}/fwd_mix_bn{mode}/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
+
+
 GLDS_GEOMS = [GEOMS16[i] for i in (0, 1, 2, 3, 4, 7, 9, 12, 13)] + [
     ("enc_k4s2p1_64to128_b9_ragged", Geom(9, 8, 8, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1, False)),   # several M tiles, a partial last one
     ("dec_k4s2p1_64to64_b5", Geom(5, 16, 16, 32, 32, 64, 64, 4, 4, 2, 2, 1, 1, True)),
@@ -202,6 +238,8 @@ def test_conv_lds_dma_tiles_bf16(name, g: Geom):
         for split in (1, 2, 3):
             with ops.force_plan(tile, split):
                 _glds_case(f"{name}/t{tile}s{split}", g)
+                if tile in (5, 7, 9):
+                    _glds_xform_case(f"{name}/t{tile}s{split}x", g)
 
 
 @pytest.mark.parametrize("n,hs,ws", [(2, 16, 16), (3, 5, 16), (2, 6, 6)], ids=["b2_16x16", "b3_5x16_partial_tile", "b2_6x6_streaming"])

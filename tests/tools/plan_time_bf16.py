@@ -1,0 +1,36 @@
+"""Time bf16 conv_fwd (plain operand) / conv_dgrad of C3's large layers under every forced tile (tuning aid, not a test).
+    python tests/tools/plan_time_bf16.py [tile ...]     tiles 0-4: register-staged, 5-10: LDS-DMA family"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
+import torch
+from mimic_amd import ops
+from mimic_amd.ops import Geom
+dev, bf = "cuda", torch.bfloat16
+B = int(os.environ.get("B", "256"))
+layers = {"rb1 64->128 @32": Geom(B, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False),
+          "rb2 128->192 @16": Geom(B, 16, 16, 32, 32, 128, 192, 4, 4, 2, 2, 1, 1, False),
+          "rb3 192->256 @8": Geom(B, 8, 8, 16, 16, 192, 256, 4, 4, 2, 2, 1, 1, False),
+          "g4 T 64->64 @64": Geom(B, 32, 32, 64, 64, 64, 64, 4, 4, 2, 2, 1, 1, True),
+          "g3 T 128->64 @32": Geom(B, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True)}
+tiles = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 9, 10]
+def fl(g, kind):
+    if kind == "fwd":
+        return 2.0 * g.N * (g.Hb * g.Wb * g.taps / (g.sh * g.sw) if g.transposed else g.Hs * g.Ws * g.taps) * g.Cin * g.Cout
+    return 2.0 * g.N * (g.Hs * g.Ws * g.taps if g.transposed else g.Hb * g.Wb * g.taps / (g.sh * g.sw)) * g.Cin * g.Cout
+for name, g in layers.items():
+    x = torch.randn(g.in_shape, device=dev).to(bf)
+    wp = (torch.randn(g.taps, g.Cin, g.Cout, device=dev) * 0.05).to(bf)
+    dy = torch.randn(g.out_shape, device=dev).to(bf)
+    for kind, fn in (("fwd", lambda: ops.conv_fwd(x, wp, g)), ("dgrad", lambda: ops.conv_dgrad(dy, wp, g))):
+        row = []
+        for tile in tiles:
+            with ops.force_plan(tile, 1):
+                for _ in range(3): fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): fn()
+                e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 10 * 1e3
+            row.append(f"t{tile}:{us:6.1f}us/{fl(g, kind) / us / 1e6:4.0f}TF")
+        print(f"{name:18s} {kind:6s} " + "  ".join(row), flush=True)
