@@ -1075,6 +1075,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs a) 
 }
 
 
+// ---- LDS-DMA family (tiles 12..15) --------------------------------------------------------------------------------------
+#include "gemm_glds_common.inc"
+#include "conv_gemm_glds.inc"
+
+
 // dest_on_small: 1 -> form 0 (Y on the small grid), 0 -> form 1 (Y on the big grid)
 static int launch_gather(const float* X, const float* W, const float* bias, float* Y, const mopoe_conv_geom* g,
                          int dest_on_small, int Ck, int Cn, int w_nk, const mopoe_bn_ref* bn_in,
@@ -1146,19 +1151,25 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 11) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..11)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 15) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..15)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
+    // 12..15 = LDS-DMA family (conv_gemm_glds.inc): vector path, K channels a multiple of 32; with BN on load the two-buffer
+    // tiles 12 and 15 only.  A plan that asks for one where it does not apply is refused (the tuner never offers it).
+    if (cfg >= 12 && (!vec || Ck % 32 != 0 || (a.bn_in.mode != 0 && cfg != 12 && cfg != 15))) {
+      set_error("conv plan: tile %d (LDS-DMA family) needs the vector path, K channels %% 32 == 0 (Ck = %d) and, with BN on load, tile 12 or 15", cfg, Ck);
+      return MOPOE_ERR_ARG;
+    }
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
     if ((cfg == 5 || cfg == 6) && Ck % 32 != 0) cfg -= 3;   // 5, 6 = tiles 2, 4 with a 32-deep K chunk
     if (cfg >= 8 && (!vec || Ck % 8 != 0 || a.mix)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels
   }
-  static const int TILE_BM[12] = {128, 256, 64, 256, 128, 64, 128, 128, 128, 256, 64, 128};
-  static const int TILE_BN[12] = {128, 64, 64, 128, 64, 64, 64, 128, 128, 64, 64, 64};
+  static const int TILE_BM[16] = {128, 256, 64, 256, 128, 64, 128, 128, 128, 256, 64, 128, 128, 128, 64, 256};
+  static const int TILE_BN[16] = {128, 64, 64, 128, 64, 64, 64, 128, 128, 64, 64, 64, 128, 64, 64, 128};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
   const int nNt = ceil_div(Cn, bn);
   // ---- split-K for grids that cannot fill the chip --------------------------------------------------------------
-  const int gbk = (cfg == 5 || cfg == 6) ? 32 : (cfg >= 8 ? 8 : 16);
+  const int gbk = (cfg == 5 || cfg == 6 || cfg >= 12) ? 32 : (cfg >= 8 ? 8 : 16);
   const int nkc = ceil_div(Ck, gbk);
   const int iters = (dest_on_small ? g->kh * g->kw : std::max(1, (g->kh / g->sh) * (g->kw / g->sw))) * nkc;
   const long blocks = nMt * nNt * nphase;
@@ -1177,13 +1188,14 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   }
   // vector path, LDS kernels: the reduction finishes in the tile's last-arriving block (gemm_epilogue_rows.inc); the
   // scalar path and the LDS-free kernels park raw slabs for splitk_epilogue_kernel
-  const bool in_kernel_reduce = vec && cfg < 8;
+  const bool in_kernel_reduce = vec && (cfg < 8 || cfg >= 12);
   if (a.partial && in_kernel_reduce) {
     if (blocks > (long)(WS_COUNTER_BYTES / sizeof(int))) { set_error("conv: split reduction over %ld output tiles (at most %zu)", blocks, WS_COUNTER_BYTES / sizeof(int)); return MOPOE_ERR_ARG; }
     a.counters = counters;
   }
   // ---- persistent M loop: at most ~1024 blocks in flight, column statistics leave a block once -------------------
-  const long persist = cfg >= 8 ? 4096 : ((cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS);   // 4-wave blocks: 3 per CU
+  const long persist = cfg >= 12 ? (cfg == 15 ? 256 : 512)       // LDS-DMA tiles: resident blocks by LDS footprint (1 or 2 per CU)
+                                 : (cfg >= 8 ? 4096 : ((cfg == 2 || cfg >= 4) ? PERSIST_BLOCKS * 3 / 2 : PERSIST_BLOCKS));   // 4-wave blocks: 3 per CU
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   // algorithmic flops: every (output pixel, tap that exists) pair
   double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
@@ -1192,8 +1204,9 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
     // algorithmic bytes: one read of the gathered activation + one write of the result
     const double abytes = ((double)g->N * a.Hx * a.Wx * Ck + (double)a.rows_total * Cn) * sizeof(float);
-    ProfScope prof(stream, flops, cfg >= 8 ? PROF_DIRECT + (cfg - 8) * 4 + spec
-                                           : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg), abytes);
+    ProfScope prof(stream, flops, cfg >= 12 ? PROF_F32_GLDS + (cfg - 12) * 3 + (spec - 1)
+                                            : (cfg >= 8 ? PROF_DIRECT + (cfg - 8) * 4 + spec
+                                                        : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg)), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
     // specialised main loops (spec != 0): vector path with Ck a multiple of the K chunk (every layer of the four
     // networks except the image-side edge layers, which do not come here, and the vocabulary projection's input gradient)
@@ -1210,7 +1223,23 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     else if (spec == 2) hipLaunchKernelGGL((direct_gemm_kernel<WM_, WN_, TI_, TJ_, 2>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
     else hipLaunchKernelGGL((direct_gemm_kernel<WM_, WN_, TI_, TJ_, 3>), grid, dim3(64 * WM_ * WN_), 0, stream, a);                \
   } while (0)
-    if (cfg == 8) MOPOE_LAUNCH_DIRECT(2, 2, 2, 2);
+#define MOPOE_LAUNCH_GLDS(BM_, BN_, WM_, WN_, ST_)                                                                                       \
+  do {                                                                                                                                \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
+    else hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
+  } while (0)
+    if (cfg >= 12) {
+      if (spec == 2) {
+        if (cfg == 12) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<128, 128, 2, 2, 2, 2>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<256, 128, 4, 2, 2, 2>), grid, dim3(512), 0, stream, a);
+      }
+      else if (cfg == 12) MOPOE_LAUNCH_GLDS(128, 128, 2, 2, 2);
+      else if (cfg == 13) MOPOE_LAUNCH_GLDS(128, 64, 2, 2, 3);
+      else if (cfg == 14) MOPOE_LAUNCH_GLDS(64, 64, 2, 2, 4);
+      else MOPOE_LAUNCH_GLDS(256, 128, 4, 2, 2);
+    }
+#undef MOPOE_LAUNCH_GLDS
+    else if (cfg == 8) MOPOE_LAUNCH_DIRECT(2, 2, 2, 2);
     else if (cfg == 9) MOPOE_LAUNCH_DIRECT(4, 1, 2, 2);
     else if (cfg == 10) MOPOE_LAUNCH_DIRECT(2, 2, 1, 1);
     else if (cfg == 11) MOPOE_LAUNCH_DIRECT(2, 1, 2, 2);

@@ -255,7 +255,9 @@ DIRECT_TILES = os.environ.get("MOPOE_DIRECT_TILES", "0") != "0"
 _conv_calls = 0
 _plans = {}
 _GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128),
-                 (128, 128), (256, 64), (64, 64), (128, 64))   # 8..11: the LDS-free kernel
+                 (128, 128), (256, 64), (64, 64), (128, 64),   # 8..11: the LDS-free kernel
+                 (128, 128), (128, 64), (64, 64), (256, 128))  # 12..15: the LDS-DMA family (csrc/conv_gemm_glds.inc)
+F32_GLDS = os.environ.get("MOPOE_F32_GLDS", "1") != "0"       # A/B switch: keep the tuner off the LDS-DMA tiles
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128)
 
 
@@ -313,7 +315,8 @@ def _gather_shape(kind: str, g: Geom):
 WS_COUNTER_BYTES = 64 << 10   # head of the workspace: arrival counters of in-kernel split reductions (header: workspace)
 
 
-def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
+def _gather_candidates(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = False):
+    """plain_operand: no BN -> ReLU on the gathered operand (every LDS-DMA tile applies; with it only tiles 12 and 15)"""
     if min(g.Cin, g.Cout) == 1:
         return {}   # image-side edge layers run on the streaming edge kernels: nothing to choose
     ws_bytes -= WS_COUNTER_BYTES
@@ -329,9 +332,11 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int):
             continue   # vector-path-only tiles
         if tile in (5, 6) and ck % 32:
             continue   # 32-deep K chunk
-        if tile >= 8 and (ck % 8 or not DIRECT_TILES):
+        if 8 <= tile < 12 and (ck % 8 or not DIRECT_TILES):
             continue   # LDS-free kernel: 8-deep K steps
-        cap = 512 if tile in (0, 1, 3) else 768          # blocks resident at once (8-wave / 4-wave tiles)
+        if tile >= 12 and not (F32_GLDS and ck % 32 == 0 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and (plain_operand or tile in (12, 15))):
+            continue   # LDS-DMA family: 32-deep stages, vector path
+        cap = (256 if tile == 15 else 512) if tile >= 12 else (512 if tile in (0, 1, 3) else 768)   # blocks resident at once
         cands[(tile, 1)] = min(1.0, blocks / cap)
         for s in _SPLITS:
             if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
@@ -521,7 +526,7 @@ def conv_fwd(x, wp, g: Geom, bn_in: Optional[Bn] = None, bias=None, mask: Option
                   stream))
 
     key = ("fwd", g, bn_in is not None, mask is not None, out_stats is not None) + (("mix",) if mix is not None else ())
-    plan = _tuned_plan(key, lambda: _gather_candidates("fwd", g, nbytes),
+    plan = _tuned_plan(key, lambda: _gather_candidates("fwd", g, nbytes, plain_operand=bn_in is None),
                        lambda ref: launch(ref, _scratch_like(out_stats)))
     launch(plan, out_stats)
     return y
@@ -564,7 +569,7 @@ def conv_dgrad(dy, wp, g: Geom, relu_bn: Optional[Bn] = None, xin=None, bwd_sums
         _check(fn(_p(dy), _p(wp), _p(dx), C.byref(gc), bnr, _p(xin), _p(sums), plan, _p(ws), C.c_size_t(nbytes), stream))
 
     key = ("dgrad", g, relu_bn is not None, bwd_sums is not None)
-    plan = _tuned_plan(key, lambda: _gather_candidates("dgrad", g, nbytes),
+    plan = _tuned_plan(key, lambda: _gather_candidates("dgrad", g, nbytes, plain_operand=True),
                        lambda ref: launch(ref, _scratch_like(bwd_sums)))
     launch(plan, bwd_sums)
     return dx
@@ -933,7 +938,10 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 104
+    names = [None] * 116
+    for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 64, 2, 2, {}, 3", "64, 64, 2, 2, {}, 4", "256, 128, 4, 2, {}, 2")):
+        for spec in (1, 2, 3):
+            names[104 + 3 * i + spec - 1] = f"gather_gemm_f32_glds_kernel<{tt.format(spec)}>"
     for i, tt in enumerate(("128", "64")):
         for xf in (0, 1):
             names[100 + 2 * i + xf] = f"wgrad_gemm_bf16_glds_kernel<{tt}, {'true' if xf else 'false'}, true>"

@@ -422,7 +422,9 @@ def _model_vs_oracle(cfg, nrow, seed, tag, mode="train_nodrop", grad_check=True)
         else:
             cos_all.append(cos)
             rel_reg.append(rel_l2)
-            ok = rel_l2 <= cap and cos >= cos_min and e_hip32 <= 1.5 * e_ref32 + 2e-2
+            # (the fp32 yardstick needs a gradient well above the noise floor: within 3 x the floor both bf16 results are
+            # mostly rounding noise and their distances to the fp32 gradient are two independent draws of it)
+            ok = rel_l2 <= cap and cos >= cos_min and (b.norm().item() <= 3 * floor or e_hip32 <= 1.5 * e_ref32 + 2e-2)
         if not ok:
             bad.append((name, round(rel_l2, 4), round(cos, 5), round(e_hip32, 4), round(e_ref32, 4), below))
     q = np.quantile(rel_reg, [0.5, 0.9])

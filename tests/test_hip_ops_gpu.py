@@ -213,8 +213,70 @@ def test_conv_every_launch_plan(name, g):
                 dw = ops.conv_wgrad(xd, dyd, g, bn_in=bnd)
             check(f"plan/{name}/wgrad_t{tile}s{split}", dw, dw_ref, rtol=5e-4, atol_rel=5e-4)
     with pytest.raises(ops.MopoeHipError):
-        with ops.force_plan(13, 1):
+        with ops.force_plan(16, 1):
             ops.conv_fwd(xd, wd, g)
+
+
+GLDS_GEOMS32 = [PLAN_GEOMS[i] for i in (0, 1, 2, 3, 5)] + [
+    ("enc_64to128_b9_ragged", Geom(9, 8, 8, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1, False)),
+    ("enc_1x1_128", Geom(2, 16, 16, 16, 16, 128, 128, 1, 1, 1, 1, 0, 0, False)),
+    ("enc_k4s4p1_16to4", Geom(2, 4, 4, 16, 16, 256, 320, 4, 4, 4, 4, 1, 1, False)),
+    ("odd_grid_T_96to32", Geom(2, 5, 6, 10, 12, 96, 32, 4, 4, 2, 2, 1, 1, True)),
+]
+
+
+@pytest.mark.parametrize("name,g", GLDS_GEOMS32, ids=[n for n, _ in GLDS_GEOMS32])
+def test_conv_lds_dma_tiles(name, g):
+    """the fp32 LDS-DMA tiles (csrc/conv_gemm_glds.inc: 12 = 128x128 / 2 buffers, 13 = 128x64 / 3, 14 = 64x64 / 4,
+    15 = 256x128 / 2) with and without a split reduction: forward with a plain operand (projection shortcut: bias +
+    statistics; element mask), forward with BN -> ReLU on load and the residual mix (tiles 12, 15), every input gradient"""
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(g.in_shape, generator=gen)
+    wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
+    bias = 0.1 * torch.randn(g.Cout, generator=gen)
+    dy = torch.randn(g.out_shape, generator=gen)
+    rows_in, rows_out = x.numel() // g.Cin, math.prod(g.out_shape[:3])
+    bn = make_bn(g.Cin, rows_in, 1, gen, x)
+    cmask = Mask((torch.rand(g.N, g.Cout, generator=gen) < 0.5).float() * 2, 1, rows_out // g.N)
+    emask = Mask((torch.rand(g.out_shape, generator=gen) < 0.5).float() * 2, 2, rows_out // g.N)
+    sres = torch.randn(g.out_shape, generator=gen)
+    bns = make_bn(g.Cout, rows_out, 1, gen, sres)
+    xd, wd, dyd, bnd, bd = x.to(DEV), wp.to(DEV), dy.to(DEV), to_dev(bn), bias.to(DEV)
+    st_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+    y_short = TB.conv_fwd(x, wp, g, bias=bias, out_stats=st_ref)
+    y_emask = TB.conv_fwd(x, wp, g, bias=bias, mask=emask)
+    stx_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+    y_x = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=stx_ref)
+    stm_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+    y_mix = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=stm_ref, mix=(sres, bns))
+    s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
+    dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
+    dx_plain = TB.conv_dgrad(dy, wp, g)
+    for tile in (12, 13, 14, 15):
+        for split in (1, 2, 5):
+            tag = f"glds/{name}/t{tile}s{split}"
+            with ops.force_plan(tile, split):
+                if g.Cin % 32 == 0:
+                    st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                    check(f"{tag}/fwd_shortcut", ops.conv_fwd(xd, wd, g, bias=bd, out_stats=st), y_short)
+                    check(f"{tag}/fwd_shortcut_stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
+                    check(f"{tag}/fwd_emask", ops.conv_fwd(xd, wd, g, bias=bd, mask=to_dev(emask)), y_emask)
+                    if tile in (12, 15):
+                        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                        check(f"{tag}/fwd_bn", ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bd, mask=to_dev(cmask), out_stats=st), y_x)
+                        check(f"{tag}/fwd_bn_stats", st, stx_ref, rtol=1e-4, atol_rel=1e-4)
+                        st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                        check(f"{tag}/fwd_mix", ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bd, mask=to_dev(cmask), out_stats=st,
+                                                             mix=(sres.to(DEV), to_dev(bns))), y_mix)
+                        check(f"{tag}/fwd_mix_stats", st, stm_ref, rtol=1e-4, atol_rel=1e-4)
+                    else:
+                        with pytest.raises(ops.MopoeHipError):
+                            ops.conv_fwd(xd, wd, g, bn_in=bnd)
+                if g.Cout % 32 == 0:
+                    s = torch.zeros(2, g.Cin, dtype=torch.float64, device=DEV)
+                    check(f"{tag}/dgrad_relubn", ops.conv_dgrad(dyd, wd, g, relu_bn=bnd, xin=xd, bwd_sums=s), dx_ref)
+                    check(f"{tag}/dgrad_sums", s, s_ref, rtol=2e-4, atol_rel=2e-4)
+                    check(f"{tag}/dgrad", ops.conv_dgrad(dyd, wd, g), dx_plain)
 
 
 def test_conv_large_rows_splitk_and_big_tiles():
