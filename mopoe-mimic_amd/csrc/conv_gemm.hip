@@ -1153,10 +1153,10 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (plan && plan->tile >= 0) {
     if (plan->tile > 15) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..15)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
-    // 12..15 = LDS-DMA family (conv_gemm_glds.inc): vector path, K channels a multiple of 32; with BN on load the two-buffer
-    // tiles 12 and 15 only.  A plan that asks for one where it does not apply is refused (the tuner never offers it).
-    if (cfg >= 12 && (!vec || Ck % 32 != 0 || (a.bn_in.mode != 0 && cfg != 12 && cfg != 15))) {
-      set_error("conv plan: tile %d (LDS-DMA family) needs the vector path, K channels %% 32 == 0 (Ck = %d) and, with BN on load, tile 12 or 15", cfg, Ck);
+    // 12..15 = LDS-DMA family (conv_gemm_glds.inc): vector path, K channels a multiple of 32; with BN on load the tiles with
+    // two or four buffers (12, 14, 15).  A plan that asks for one where it does not apply is refused (the tuner never offers it).
+    if (cfg >= 12 && (!vec || Ck % 32 != 0 || (a.bn_in.mode != 0 && cfg == 13))) {
+      set_error("conv plan: tile %d (LDS-DMA family) needs the vector path, K channels %% 32 == 0 (Ck = %d) and, with BN on load, tile 12, 14 or 15", cfg, Ck);
       return MOPOE_ERR_ARG;
     }
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
@@ -1231,6 +1231,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if (cfg >= 12) {
       if (spec == 2) {
         if (cfg == 12) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<128, 128, 2, 2, 2, 2>), grid, dim3(256), 0, stream, a);
+        else if (cfg == 14) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<64, 64, 2, 2, 2, 4>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<256, 128, 4, 2, 2, 2>), grid, dim3(512), 0, stream, a);
       }
       else if (cfg == 12) MOPOE_LAUNCH_GLDS(128, 128, 2, 2, 2);
@@ -1346,8 +1347,13 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   a.fast = (vec && ((g->Ws % BK == 0) || (BK % g->Ws == 0 && hw_s % BK == 0))) ? 1 : 0;
   const int taps = g->kh * g->kw;
   bool big = g->Cin > 64 && g->Cout > 64;
-  if (plan && plan->tile == 2) big = false;   // the plan may ask for 64x64 tiles on wide layers too (tile 0 = 128x128 needs both > 64)
-  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0 or 2)", plan->tile); return MOPOE_ERR_ARG; }
+  // plan tiles: 0 = 128x128, 2 = 64x64 (register-staged, 16 pixels per chunk); 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per
+  // stage: conv_gemm_glds.inc; vector path only)
+  if (plan && (plan->tile == 2 || plan->tile == 6)) big = false;   // the plan may ask for 64x64 tiles on wide layers too
+  else if (plan && plan->tile == 5) big = true;
+  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6)", plan->tile); return MOPOE_ERR_ARG; }
+  const bool glds = plan && plan->tile >= 5;
+  if (glds && !vec) { set_error("wgrad plan: the LDS-DMA tiles need the vector path (channel counts %% 4 == 0, aligned tensors)"); return MOPOE_ERR_ARG; }
   const int T = big ? 128 : 64;
   const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
   a.nJ = nJ;
@@ -1355,11 +1361,12 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   // split the pixel reduction until ~1024 blocks are in flight, keeping >= 8 K-chunks per block
   long split = (1024 + tiles - 1) / tiles;
   if (plan && plan->split > 0) split = plan->split;
-  const long max_split = (a.Ms + 8 * BK - 1) / (8 * BK);
+  const int kp = glds ? 32 : BK;                  // pixels per chunk
+  const long max_split = glds ? (a.Ms + 4 * kp - 1) / (4 * kp) : (a.Ms + 8 * BK - 1) / (8 * BK);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   long chunk = (a.Ms + split - 1) / split;
-  chunk = (chunk + BK - 1) / BK * BK;
+  chunk = (chunk + kp - 1) / kp * kp;
   split = (a.Ms + chunk - 1) / chunk;
   a.chunk = chunk;
   a.atomic = split > 1;
@@ -1373,9 +1380,19 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   const int spec = a.fast ? (a.bn_in.mode != 0 ? 2 : 1) : 0;
   const double abytes = ((double)g->N * g->Hs * g->Ws * (g->transposed ? g->Cin : g->Cout)
                          + (double)g->N * g->Hb * g->Wb * (g->transposed ? g->Cout : g->Cin)) * sizeof(float);   // both operands, once
-  ProfScope prof(stream, flops, vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1), abytes);
+  ProfScope prof(stream, flops, glds ? PROF_F32_WGRAD_GLDS + (big ? 0 : 2) + (a.bn_in.mode != 0 ? 1 : 0)
+                                     : (vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1)), abytes);
   dim3 grid(nI * nJ, taps, (unsigned)split);
-  if (vec) {
+  if (glds) {
+    const bool xf = a.bn_in.mode != 0;
+    if (big) {
+      if (xf) hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<128, true, 2>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<128, false, 2>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (xf) hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<64, true, 2>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<64, false, 4>), grid, dim3(256), 0, stream, a);
+    }
+  } else if (vec) {
     if (big) {
       if (spec == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 1>), grid, dim3(256), 0, stream, a);
       else if (spec == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, true, 2>), grid, dim3(256), 0, stream, a);

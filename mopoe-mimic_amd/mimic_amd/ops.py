@@ -316,7 +316,7 @@ WS_COUNTER_BYTES = 64 << 10   # head of the workspace: arrival counters of in-ke
 
 
 def _gather_candidates(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = False):
-    """plain_operand: no BN -> ReLU on the gathered operand (every LDS-DMA tile applies; with it only tiles 12 and 15)"""
+    """plain_operand: no BN -> ReLU on the gathered operand (every LDS-DMA tile applies; with it tiles 12, 14 and 15)"""
     if min(g.Cin, g.Cout) == 1:
         return {}   # image-side edge layers run on the streaming edge kernels: nothing to choose
     ws_bytes -= WS_COUNTER_BYTES
@@ -334,8 +334,8 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = 
             continue   # 32-deep K chunk
         if 8 <= tile < 12 and (ck % 8 or not DIRECT_TILES):
             continue   # LDS-free kernel: 8-deep K steps
-        if tile >= 12 and not (F32_GLDS and ck % 32 == 0 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and (plain_operand or tile in (12, 15))):
-            continue   # LDS-DMA family: 32-deep stages, vector path
+        if tile >= 12 and not (F32_GLDS and ck % 32 == 0 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and (plain_operand or tile != 13)):
+            continue   # LDS-DMA family: 32-deep stages, vector path (with BN on load: the tiles with 2 or 4 buffers)
         cap = (256 if tile == 15 else 512) if tile >= 12 else (512 if tile in (0, 1, 3) else 768)   # blocks resident at once
         cands[(tile, 1)] = min(1.0, blocks / cap)
         for s in _SPLITS:
@@ -349,8 +349,9 @@ def _wgrad_candidates(g: Geom, bf16: bool = False):
         return {}
     ms = g.N * g.Hs * g.Ws
     cands = {}
-    # bf16: tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_bf16_glds.inc)
-    for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if bf16 and BF16_GLDS else ((0, 128), (2, 64))):
+    # tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_glds.inc, conv_gemm_bf16_glds.inc)
+    glds = (BF16_GLDS if bf16 else F32_GLDS and g.Cin % 4 == 0 and g.Cout % 4 == 0)
+    for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))):
         if tsz == 128 and (g.Cin <= 64 or g.Cout <= 64):
             continue
         tiles = -(-g.Cin // tsz) * -(-g.Cout // tsz) * g.taps
@@ -938,7 +939,10 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 116
+    names = [None] * 120
+    for i, (tt, st) in enumerate((("128", (2, 2)), ("64", (4, 2)))):
+        for xf in (0, 1):
+            names[116 + 2 * i + xf] = f"wgrad_gemm_f32_glds_kernel<{tt}, {'true' if xf else 'false'}, {st[xf]}>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 64, 2, 2, {}, 3", "64, 64, 2, 2, {}, 4", "256, 128, 4, 2, {}, 2")):
         for spec in (1, 2, 3):
             names[104 + 3 * i + spec - 1] = f"gather_gemm_f32_glds_kernel<{tt.format(spec)}>"
