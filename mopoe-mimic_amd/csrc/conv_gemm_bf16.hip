@@ -556,7 +556,7 @@ static int ilog2_exact(long v) {
 // tiles: 0 = 128x128 (4 waves)  1 = 256x64 (4 waves)  2 = 64x64 (4 waves)  3 = 256x128 (8 waves)  4 = 128x64 (4 waves)
 // LDS-DMA family (conv_gemm_bf16_glds.inc; operands without a transform on load, K channels a multiple of 64):
 //   5 = 128x128, 2 buffers   6 = 128x128, 3 buffers   7 = 256x128 (8 waves), 2 buffers   8 = 256x128, 3 buffers
-//   9 = 128x64, 2 buffers   10 = 128x64, 3 buffers   11 = 256x64 (8 waves as 4x2... see GLDS_TILES), 3 buffers
+//   9 = 128x64, 2 buffers   10 = 128x64, 3 buffers   11 = 64x64, 4 buffers (the deep layers: few rows, long reductions)
 constexpr int BF16_NTILES = 12;
 static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bias, void* Y, int out_f32,
                               const mopoe_conv_geom* g, int dest_on_small, int Ck, int Cn, int w_nk,
@@ -626,7 +626,7 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
     }
     cfg = plan->tile;
   }
-  static const int TILE_BM[BF16_NTILES] = {128, 256, 64, 256, 128, 128, 128, 256, 256, 128, 128, 256};
+  static const int TILE_BM[BF16_NTILES] = {128, 256, 64, 256, 128, 128, 128, 256, 256, 128, 128, 64};
   static const int TILE_BN[BF16_NTILES] = {128, 64, 64, 128, 64, 128, 128, 128, 128, 64, 64, 64};
   const int bm = TILE_BM[cfg], bn = TILE_BN[cfg];
   const long nMt = ceil_div(a.rows_per_phase, bm);
@@ -657,7 +657,7 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   }
   // resident blocks: 8-wave tiles 2 per CU, 4-wave register-staged tiles 3 per CU; the LDS-DMA tiles by their LDS footprint
   // (64 KB -> 2 per CU, 48 KB -> 3 per CU, 96 KB and more -> 1 per CU)
-  static const int GLDS_PER_CU[BF16_NTILES] = {0, 0, 0, 0, 0, 2, 1, 1, 1, 3, 2, 1};
+  static const int GLDS_PER_CU[BF16_NTILES] = {0, 0, 0, 0, 0, 2, 1, 1, 1, 3, 2, 2};
   const long persist = cfg >= 5 ? 256L * GLDS_PER_CU[cfg] : (cfg == 3 ? PERSIST_BLOCKS_BF16 : PERSIST_BLOCKS_BF16 * 3 / 2);
   long gx = std::min<long>(nMt, std::max<long>(1, persist / ((long)nNt * nphase * a.nsplit)));
   const double taps_eff = dest_on_small ? (double)g->kh * g->kw : (double)g->kh * g->kw / ((double)g->sh * g->sw);
@@ -686,7 +686,7 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
       else if (cfg == 8) MOPOE_LAUNCH_G(256, 128, 4, 2, 3);
       else if (cfg == 9) MOPOE_LAUNCH_G(128, 64, 4, 1, 2);
       else if (cfg == 10) MOPOE_LAUNCH_G(128, 64, 4, 1, 3);
-      else MOPOE_LAUNCH_G(256, 64, 4, 2, 3);
+      else MOPOE_LAUNCH_G(64, 64, 2, 2, 4);
       if (int rc = check_launch("gather_gemm_bf16_glds")) return rc;
       return MOPOE_OK;
     }

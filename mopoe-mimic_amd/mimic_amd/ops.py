@@ -426,8 +426,8 @@ def _tuned_plan(key, cands_fn, launch):
 BF16 = torch.bfloat16
 _GATHER_TILES_BF16 = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64),
                       # 5..11: the LDS-DMA family (csrc/conv_gemm_bf16_glds.inc): operands without a transform on load, K % 64 == 0
-                      (128, 128), (128, 128), (256, 128), (256, 128), (128, 64), (128, 64), (256, 64))
-_GLDS_TILES = {5: 512, 6: 256, 7: 256, 9: 768, 10: 512}     # tile -> blocks resident at once (8 and 11 spill: not offered)
+                      (128, 128), (128, 128), (256, 128), (256, 128), (128, 64), (128, 64), (64, 64))
+_GLDS_TILES = {5: 512, 6: 256, 7: 256, 9: 768, 10: 512, 11: 512}     # tile -> blocks resident at once (8 spills: not offered)
 BF16_GLDS = os.environ.get("MOPOE_BF16_GLDS", "1") != "0"      # A/B switch: keep the tuner on the register-staged tiles
 
 
@@ -952,7 +952,7 @@ def _prof_kind_names():
     for i, tt in enumerate(("128, 128, 2, 2, 2, 2", "256, 128, 4, 2, 2, 2", "128, 64, 4, 1, 2, 2")):
         names[94 + i] = f"gather_gemm_bf16_glds_kernel<{tt}>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 128, 2, 2, {}, 3", "256, 128, 4, 2, {}, 2", "256, 128, 4, 2, {}, 3",
-                            "128, 64, 4, 1, {}, 2", "128, 64, 4, 1, {}, 3", "256, 64, 4, 2, {}, 3")):
+                            "128, 64, 4, 1, {}, 2", "128, 64, 4, 1, {}, 3", "64, 64, 2, 2, {}, 4")):
         for k, spec in enumerate((1, 3)):
             names[80 + 2 * i + k] = f"gather_gemm_bf16_glds_kernel<{tt.format(spec)}>"
     for tile, tt in enumerate(("128, 128, 2, 2", "256, 64, 4, 1", "64, 64, 2, 2", "256, 128, 4, 2", "128, 64, 4, 1")):

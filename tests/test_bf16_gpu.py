@@ -232,9 +232,9 @@ GLDS_GEOMS = [GEOMS16[i] for i in (0, 1, 2, 3, 4, 7, 9, 12, 13)] + [
 
 @pytest.mark.parametrize("name,g", GLDS_GEOMS, ids=[n for n, _ in GLDS_GEOMS])
 def test_conv_lds_dma_tiles_bf16(name, g: Geom):
-    """every LDS-DMA tile (two and three LDS buffers; 128x128, 256x128, 128x64) with and without a split reduction against
+    """every LDS-DMA tile (two to four LDS buffers; 128x128, 256x128, 128x64, 64x64) with and without a split reduction against
     the emulation, and against the register-staged kernel's result bit for bit where the summation order is the same"""
-    for tile in (5, 6, 7, 9, 10):
+    for tile in (5, 6, 7, 9, 10, 11):
         for split in (1, 3):
             with ops.force_plan(tile, split):
                 _glds_case(f"{name}/t{tile}s{split}", g)
