@@ -53,10 +53,9 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v;
-  v[0] = (__bf16)lo;
-  v[1] = (__bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 f = {lo, hi};      // converted as a vector: ONE v_cvt_pk_bf16_f32 (two scalar conversions cost two + a v_perm)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
 // the value a float has after a round trip through bf16 storage

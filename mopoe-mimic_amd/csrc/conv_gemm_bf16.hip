@@ -89,14 +89,26 @@ __device__ __forceinline__ uint4 bldq(__amdgpu_buffer_rsrc_t srd, unsigned byte_
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// 8 bf16 (one uint4) -> relu(x * scale + shift) -> 8 bf16; zero when !ok (spatial padding stays zero AFTER the transform)
+// 8 bf16 (one uint4) -> relu(x * scale + shift) -> 8 bf16; zero when !ok (spatial padding stays zero AFTER the transform).
+// Six VALU instructions per pair instead of eight: one packed fp32 fma, one packed conversion (round to nearest even), and the
+// ReLU on the packed result as a signed 16-bit max (rounding keeps the sign, so relu(round(y)) == round(relu(y)); -0 becomes +0)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bn_relu2(unsigned u, float s0, float s1, float t0, float t1) {
+  f32x2 x, s, t;
+  x.x = bf16_lo(u); x.y = bf16_hi(u);
+  s.x = s0; s.y = s1; t.x = t0; t.y = t1;
+  const f32x2 y = __builtin_elementwise_fma(x, s, t);
+  const s16x2 p = __builtin_bit_cast(s16x2, pack_bf16(y.x, y.y));
+  const s16x2 zero = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(p, zero));
+}
 __device__ __forceinline__ uint4 bn_relu8(uint4 u, const float4& sc0, const float4& sc1, const float4& sh0, const float4& sh1, bool ok) {
-  auto f = [](float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.f); };
   uint4 r;
-  r.x = pack_bf16(f(bf16_lo(u.x), sc0.x, sh0.x), f(bf16_hi(u.x), sc0.y, sh0.y));
-  r.y = pack_bf16(f(bf16_lo(u.y), sc0.z, sh0.z), f(bf16_hi(u.y), sc0.w, sh0.w));
-  r.z = pack_bf16(f(bf16_lo(u.z), sc1.x, sh1.x), f(bf16_hi(u.z), sc1.y, sh1.y));
-  r.w = pack_bf16(f(bf16_lo(u.w), sc1.z, sh1.z), f(bf16_hi(u.w), sc1.w, sh1.w));
+  r.x = bn_relu2(u.x, sc0.x, sc0.y, sh0.x, sh0.y);
+  r.y = bn_relu2(u.y, sc0.z, sc0.w, sh0.z, sh0.w);
+  r.z = bn_relu2(u.z, sc1.x, sc1.y, sh1.x, sh1.y);
+  r.w = bn_relu2(u.w, sc1.z, sc1.w, sh1.z, sh1.w);
   return ok ? r : make_uint4(0u, 0u, 0u, 0u);
 }
 
@@ -615,13 +627,13 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   int cfg;
   if (Cn > 64) cfg = a.rows_per_phase >= 256L * 128 ? 3 : (a.rows_per_phase > 64 ? 0 : 2);
   else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
-  const bool glds_ok = Ck % 64 == 0;     // (with BN on load: the two-buffer tiles 5, 7, 9 only)
+  const bool glds_ok = Ck % 64 == 0;     // (with BN on load: tiles 5, 7, 9 (two buffers) and 11 (four; the three-buffer forms exceed 256 registers))
   static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");   // (A/B switch for the static heuristic)
   if (glds_ok && glds_default) cfg = cfg == 0 ? 5 : (cfg == 3 ? 7 : (cfg == 4 ? 9 : cfg));
   if (plan && plan->tile >= 0) {
     if (plan->tile >= BF16_NTILES) { set_error("bf16 conv plan: tile %d (0..%d)", plan->tile, BF16_NTILES - 1); return MOPOE_ERR_ARG; }
-    if (plan->tile >= 5 && (!glds_ok || (a.bn_in.mode != 0 && plan->tile != 5 && plan->tile != 7 && plan->tile != 9))) {
-      set_error("bf16 conv plan: tile %d (LDS-DMA family) needs K channels %% 64 == 0 (Ck = %d) and, with BN on load, one of the two-buffer tiles 5, 7, 9", plan->tile, Ck);
+    if (plan->tile >= 5 && (!glds_ok || (a.bn_in.mode != 0 && (plan->tile == 6 || plan->tile == 8 || plan->tile == 10)))) {
+      set_error("bf16 conv plan: tile %d (LDS-DMA family) needs K channels %% 64 == 0 (Ck = %d) and, with BN on load, one of the tiles 5, 7, 9, 11", plan->tile, Ck);
       return MOPOE_ERR_ARG;
     }
     cfg = plan->tile;
@@ -665,7 +677,8 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   {
     const int spec = w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1);
     const double abytes = (double)xb + (double)a.rows_total * Cn * (out_f32 ? 4.0 : 2.0);
-    ProfScope prof(stream, flops, cfg >= 5 ? (spec == 2 ? PROF_BF16_GLDS_X + (cfg - 5) / 2 : PROF_BF16_GLDS + (cfg - 5) * 2 + (spec == 3 ? 1 : 0))
+    static const int GLDS_X_SLOT[BF16_NTILES] = {0, 0, 0, 0, 0, 0, 0, 1, 0, 2, 3, 4};
+    ProfScope prof(stream, flops, cfg >= 5 ? (spec == 2 ? PROF_BF16_GLDS_X + GLDS_X_SLOT[cfg] : PROF_BF16_GLDS + (cfg - 5) * 2 + (spec == 3 ? 1 : 0))
                                            : PROF_BF16_GATHER + cfg * 3 + (spec - 1), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
 #define MOPOE_LAUNCH_G(BM_, BN_, WM_, WN_, ST_)                                                                                           \
@@ -673,12 +686,13 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
     if (spec == 1) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
     else hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
   } while (0)
-#define MOPOE_LAUNCH_GX(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 2, 2>), grid, dim3(64 * WM_ * WN_), 0, stream, a)
+#define MOPOE_LAUNCH_GX(BM_, BN_, WM_, WN_, ST_) hipLaunchKernelGGL((gather_gemm_bf16_glds_kernel<BM_, BN_, WM_, WN_, 2, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a)
     if (cfg >= 5) {
       if (spec == 2) {
-        if (cfg == 5) MOPOE_LAUNCH_GX(128, 128, 2, 2);
-        else if (cfg == 7) MOPOE_LAUNCH_GX(256, 128, 4, 2);
-        else MOPOE_LAUNCH_GX(128, 64, 4, 1);
+        if (cfg == 5) MOPOE_LAUNCH_GX(128, 128, 2, 2, 2);
+        else if (cfg == 7) MOPOE_LAUNCH_GX(256, 128, 4, 2, 2);
+        else if (cfg == 9) MOPOE_LAUNCH_GX(128, 64, 4, 1, 2);
+        else MOPOE_LAUNCH_GX(64, 64, 2, 2, 4);
       }
       else if (cfg == 5) MOPOE_LAUNCH_G(128, 128, 2, 2, 2);
       else if (cfg == 6) MOPOE_LAUNCH_G(128, 128, 2, 2, 3);

@@ -446,8 +446,8 @@ def _gather_candidates_bf16(kind: str, g: Geom, ws_bytes: int, plain_operand: bo
         blocks = -(-rows // bm) * -(-cn // bn) * nphase
         if bm == 256 and rows < 256:
             continue
-        if tile >= 5 and not (BF16_GLDS and ck % 64 == 0 and tile in _GLDS_TILES and (plain_operand or tile in (5, 7, 9))):
-            continue     # (with BN -> ReLU on load only the two-buffer tiles exist)
+        if tile >= 5 and not (BF16_GLDS and ck % 64 == 0 and tile in _GLDS_TILES and (plain_operand or tile in (5, 7, 9, 11))):
+            continue     # (with BN -> ReLU on load: the two-buffer tiles and the four-buffer small one)
         if tile >= 5 and taps * (ck // 64) < 2:
             continue     # a single 64-deep chunk per tile: nothing to pipeline
         cap = _GLDS_TILES[tile] if tile >= 5 else (512 if tile == 3 else 768)

@@ -238,7 +238,7 @@ def test_conv_lds_dma_tiles_bf16(name, g: Geom):
         for split in (1, 3):
             with ops.force_plan(tile, split):
                 _glds_case(f"{name}/t{tile}s{split}", g)
-                if tile in (5, 7, 9):
+                if tile in (5, 7, 9, 11):
                     _glds_xform_case(f"{name}/t{tile}s{split}x", g)
 
 

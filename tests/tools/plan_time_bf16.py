@@ -15,16 +15,27 @@ layers = {"rb1 64->128 @32": Geom(B, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, 
           "g3 T 128->64 @32": Geom(B, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True)}
 tiles = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 9, 10]
 def fl(g, kind):
-    if kind == "fwd":
+    if kind.startswith("fwd"):
         return 2.0 * g.N * (g.Hb * g.Wb * g.taps / (g.sh * g.sw) if g.transposed else g.Hs * g.Ws * g.taps) * g.Cin * g.Cout
     return 2.0 * g.N * (g.Hs * g.Ws * g.taps if g.transposed else g.Hb * g.Wb * g.taps / (g.sh * g.sw)) * g.Cin * g.Cout
 for name, g in layers.items():
     x = torch.randn(g.in_shape, device=dev).to(bf)
     wp = (torch.randn(g.taps, g.Cin, g.Cout, device=dev) * 0.05).to(bf)
     dy = torch.randn(g.out_shape, device=dev).to(bf)
-    for kind, fn in (("fwd", lambda: ops.conv_fwd(x, wp, g)), ("dgrad", lambda: ops.conv_dgrad(dy, wp, g))):
+    rows_in = x.numel() // g.Cin
+    bn = ops.Bn(torch.rand(g.Cin, device=dev) + 0.5, torch.randn(g.Cin, device=dev) * 0.1, 1,
+                torch.stack([x.float().reshape(-1, g.Cin).sum(0), (x.float() ** 2).reshape(-1, g.Cin).sum(0)]).double(), rows_in)
+    st = torch.zeros(2, g.Cout, dtype=torch.float64, device=dev)
+    kinds = (("fwd", lambda: ops.conv_fwd(x, wp, g)), ("fwd+bn", lambda: ops.conv_fwd(x, wp, g, bn_in=bn, out_stats=st)),
+             ("dgrad", lambda: ops.conv_dgrad(dy, wp, g)))
+    for kind, fn in kinds:
+        if os.environ.get("KINDS") and kind not in os.environ["KINDS"].split(","):
+            continue
         row = []
         for tile in tiles:
+            if kind == "fwd+bn" and tile in (6, 8, 10):
+                row.append(f"t{tile}:   n/a        ")
+                continue
             with ops.force_plan(tile, 1):
                 for _ in range(3): fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
