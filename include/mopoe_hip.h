@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 12
+#define MOPOE_ABI_VERSION 13
 
 /* error codes */
 #define MOPOE_OK 0
@@ -152,6 +152,11 @@ int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, const mopoe_co
  * out_stats (optional) += {sum, sumsq} of out (feeds the next block's bn1). */
 int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
                         const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream);
+
+/* out = relu(bn(x)): the operand of a block's second conv written out once (the BatchNorm + ReLU in front of the k4
+ * conv, ResidualBlocks.py:26-29,58-61,90-93,124-127), for the layers where the conv's BN -> ReLU-on-load form costs more
+ * than this pass (the up-sampling convs); the conv and its weight gradient then take `out` as a plain operand. */
+int mopoe_bn_relu_apply(const float* x, float* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn, void* stream);
 
 /* sums += {sum g, sum g*shat} over rows: the reductions for the shortcut BatchNorm's backward. */
 int mopoe_bn_bwd_reduce(const float* g, const float* s, int64_t rows, int32_t C,
@@ -320,6 +325,7 @@ int mopoe_edge_wgrad_bf16(const uint16_t* vec, const float* scal, float* dw, con
 int mopoe_edge_reduce_bf16(const uint16_t* x, const float* w, const float* bias, float* out, const mopoe_conv_geom* g,
                            int32_t C, void* stream);
 /* residual-block glue on bf16 tensors (same arithmetic in fp32 registers; results rounded once when stored) */
+int mopoe_bn_relu_apply_bf16(const uint16_t* x, uint16_t* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn, void* stream);
 int mopoe_block_out_fwd_bf16(const uint16_t* s, const uint16_t* m, uint16_t* out, int64_t rows, int32_t C,
                              const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream);
 int mopoe_bn_bwd_reduce_bf16(const uint16_t* g, const uint16_t* s, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s,

@@ -114,6 +114,49 @@ __global__ __launch_bounds__(EW_THREADS) void block_out_fwd_kernel(const T* __re
   }
 }
 
+// ---- out = relu(bn(x)) ------------------------------------------------------------------------------------
+// The operand of a block's second conv, written out once where reading it through the conv's BN -> ReLU-on-load form costs
+// more than one more pass over it (the up-sampling convs: every input element is gathered by 16 (tap, phase) pairs and K
+// per tile is too short to hide the register-staged loads -- DESIGN section 4).  Same arithmetic and the same rounding point
+// as the on-load transform: fmaf, max, one rounding when stored.
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(EW_THREADS) void bn_relu_apply_kernel(const T* __restrict__ x, T* __restrict__ out, long rows, int C,
+                                                                 mopoe_bn_ref bn) {
+  const ColLayout L(C, VEC);
+  __shared__ float cf[4][EW_COEF_C];
+  coef_table<4>(bn, nullptr, C, cf);
+  for (int cbase = 0; cbase < L.Cv; cbase += L.cols) {
+    const int cv = cbase + L.tc;
+    const bool active = cv < L.Cv && L.tr < L.rpp;
+    float sc[VEC], sh[VEC];
+    for (int e = 0; e < VEC; ++e) {
+      sc[e] = sh[e] = 0.f;
+      const int c = cv * VEC + e;
+      if (active && c < C) { float k[6]; coef_get<4>(bn, nullptr, c, C, cf, k); sc[e] = k[2]; sh[e] = k[3]; }
+    }
+    if (active) {
+      const long step = (long)gridDim.x * L.rpp * U;
+      for (long rb = (long)blockIdx.x * L.rpp * U + L.tr; rb < rows; rb += step) {
+        typename VecT<T, VEC>::Raw vx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          vx[u] = VecT<T, VEC>::ldr(x + (r < rows ? r : rows - 1) * C + (long)cv * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long r = rb + (long)u * L.rpp;
+          if (r >= rows) break;
+          const VecT<T, VEC> w = VecT<T, VEC>::un(vx[u]);
+          VecT<T, VEC> o;
+          for (int e = 0; e < VEC; ++e) o.v[e] = stored<T>(fmaxf(fmaf(w.v[e], sc[e], sh[e]), 0.f));
+          o.st(out + r * C + (long)cv * VEC);
+        }
+      }
+    }
+  }
+}
+
 // ---- sums += {sum g, sum g*shat} -----------------------------------------------------------------------
 template <typename T, int VEC, int U>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ s, long rows,
@@ -402,6 +445,21 @@ static bool ew_wide_ok(int C, std::initializer_list<const void*> ptrs, const cha
 }
 
 template <typename T>
+static int bn_relu_apply_t(const T* x, T* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn, void* stream) {
+  EW_ARGCHECK(x && out && bn && bn->mode != 0 && bn->C == C && rows > 0, "bn_relu_apply: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  constexpr int W = EwVec<T>::wide;
+#define MOPOE_L(U_) hipLaunchKernelGGL((bn_relu_apply_kernel<T, W, U_>), dim3(ew_grid(rows, C, W)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C, *bn)
+  if (ew_wide_ok<T>(C, {x, out}, "bn_relu_apply", &rc)) { EW_DISPATCH_U(MOPOE_L) }
+#undef MOPOE_L
+  else if constexpr (std::is_same<T, float>::value)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<float, 1, 1>), dim3(ew_grid(rows, C, 1)), dim3(EW_THREADS), 0, st, x, out, (long)rows, C, *bn);
+  else return rc;
+  return check_launch("bn_relu_apply");
+}
+
+template <typename T>
 static int block_out_fwd_t(const T* s, const T* m, T* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn_s, float a,
                            float b, double* out_stats, void* stream) {
   EW_ARGCHECK(s && m && out && bn_s && bn_s->mode != 0 && bn_s->C == C && rows > 0, "block_out_fwd: bad arguments");
@@ -496,6 +554,13 @@ static int colsum_t(const T* x, float* out, int64_t rows, int32_t C, int32_t out
   return check_launch("colsum");
 }
 
+extern "C" int mopoe_bn_relu_apply(const float* x, float* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn, void* stream) {
+  return bn_relu_apply_t<float>(x, out, rows, C, bn, stream);
+}
+extern "C" int mopoe_bn_relu_apply_bf16(const uint16_t* x, uint16_t* out, int64_t rows, int32_t C, const mopoe_bn_ref* bn,
+                                        void* stream) {
+  return bn_relu_apply_t<bf16_t>(x, out, rows, C, bn, stream);
+}
 extern "C" int mopoe_block_out_fwd(const float* s, const float* m, float* out, int64_t rows, int32_t C,
                                    const mopoe_bn_ref* bn_s, float a, float b, double* out_stats, void* stream) {
   return block_out_fwd_t<float>(s, m, out, rows, C, bn_s, a, b, out_stats, stream);

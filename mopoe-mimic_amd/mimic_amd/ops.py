@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -623,6 +623,15 @@ def block_out_fwd(s, m, bn_s: Bn, a=RES_A, b=RES_B, out_stats=None):
     fn = lib().mopoe_block_out_fwd_bf16 if _is16(s) else lib().mopoe_block_out_fwd
     _check(fn(_p(s), _p(m), _p(out), C.c_int64(_rows(s)), s.shape[-1], _bn(bn_s),
                                      C.c_float(a), C.c_float(b), _p(out_stats), _stream()))
+    return out
+
+
+def bn_relu_apply(x, bn: Bn):
+    """relu(bn(x)) written out (the operand of a block's second conv, where that beats the conv's BN -> ReLU-on-load form)"""
+    _dev(x)
+    out = torch.empty_like(x)
+    fn = lib().mopoe_bn_relu_apply_bf16 if _is16(x) else lib().mopoe_bn_relu_apply
+    _check(fn(_p(x), _p(out), C.c_int64(_rows(x)), x.shape[-1], _bn(bn), _stream()))
     return out
 
 

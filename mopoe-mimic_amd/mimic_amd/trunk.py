@@ -153,6 +153,23 @@ class StatsArena:
         return v
 
 
+# MOPOE_MATERIALIZE: whether the second conv of a block takes relu(bn2(d1)) written out once by ops.bn_relu_apply (the conv and
+# its weight gradient then run their plain-operand forms: all-DMA, deeper pipelines) instead of applying it on the operand
+# load.  "auto" (default): in the bf16 family, where the on-load forms lose most (measured, 1 x MI355X: C3 20 488 -> 21 036
+# samples/s, C5 4 745 -> 4 860; fp32 C2 5 616 vs 5 608-5 642, i.e. nothing: left on load there); "1" always, "0" never.
+# Doing the same for conv1's operand costs more than it gives (C3 20 677, C5 4 770: its input is the block's big input and
+# the 1x1 conv is HBM-bound already).
+MATERIALIZE = os.environ.get("MOPOE_MATERIALIZE", "auto")
+
+
+def _materialize(g2, d1) -> bool:
+    if MATERIALIZE == "0":
+        return False
+    if MATERIALIZE == "1":
+        return True
+    return d1.dtype in (torch.bfloat16, torch.float16)
+
+
 def _master_weight(mod):
     return mod.weight
 
@@ -199,12 +216,15 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         if training:
             running.append((st_s, sbn, rows_out))
         st_out = arena.take(g2.Cout)
+        # conv2's operand relu(bn2(d1)): applied on the operand load, or written out once (a2) and taken as it lies
+        a2 = ops.bn_relu_apply(d1, bn2) if _materialize(g2, d1) else None
+        op2, bn_in2 = (d1, bn2) if a2 is None else (a2, None)
         if FUSE_MIX and ops.conv_mix_supported(d1, g2):
-            out = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2, mix=(s, bns), out_stats=st_out)
+            out = ops.conv_fwd(op2, wsel(p.conv2), g2, bn_in=bn_in2, bias=p.conv2.bias, mask=mask2, mix=(s, bns), out_stats=st_out)
         else:
-            m = ops.conv_fwd(d1, wsel(p.conv2), g2, bn_in=bn2, bias=p.conv2.bias, mask=mask2)
+            m = ops.conv_fwd(op2, wsel(p.conv2), g2, bn_in=bn_in2, bias=p.conv2.bias, mask=mask2)
             out = ops.block_out_fwd(s, m, bns, out_stats=st_out)
-        saved.append(dict(x=x, d1=d1, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2))
+        saved.append(dict(x=x, d1=d1, a2=a2, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2))
         x, x_stats = out, st_out
     return x, saved, running
 
@@ -276,7 +296,11 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         sums2 = take_d(g1.Cout)
         dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
         w2, ws_ = take_w(g2), take_w(g2)
-        grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=w2), d1, dm)
+        a2 = sv.get("a2")
+        if a2 is None:
+            grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=w2), d1, dm)
+        else:
+            grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(a2, dm, g2, out=w2), a2, dm)
         grads[f"{n}.{p.short_name}.0.weight"] = lane.run(lambda: ops.conv_wgrad(x, ds, g2, out=ws_), x, ds)
         dxs = lane_s.run(lambda: ops.conv_dgrad(ds, wsel(p.short[0]), g2), ds)
         grads[f"{n}.{p.short_name}.0.bias"] = cds

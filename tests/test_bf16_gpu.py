@@ -278,6 +278,7 @@ def test_block_glue_bf16(rows, c):
     bn = make_bn(c, rows, 1, gen, s.float())
     sd, md, gd, bnd = s.to(DEV), m.to(DEV), g.to(DEV), to_dev(bn)
     st_ref, st = torch.zeros(2, c, dtype=torch.float64), torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    check16("bn_relu_apply", ops.bn_relu_apply(sd, bnd), TB.bn_relu_apply(s, bn))
     check16("block_out_fwd", ops.block_out_fwd(sd, md, bnd, out_stats=st), TB.block_out_fwd(s, m, bn, out_stats=st_ref))
     check("block_out_fwd/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
     sums_ref = TB.bn_bwd_reduce(g, s, bn)

@@ -314,6 +314,7 @@ def test_block_glue(rows, c):
         st = torch.zeros(2, c, dtype=torch.float64, device=DEV)
         out = ops.block_out_fwd(s.to(DEV), m.to(DEV), to_dev(bn), out_stats=st)
         check(f"block_out_fwd[{rows}x{c}]bn{mode}", out, out_ref)
+        check(f"bn_relu_apply[{rows}x{c}]bn{mode}", ops.bn_relu_apply(s.to(DEV), to_dev(bn)), TB.bn_relu_apply(s, bn))
         check(f"block_out_fwd[{rows}x{c}]bn{mode}/stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
         sums_ref = TB.bn_bwd_reduce(g, s, bn)
         sums = ops.bn_bwd_reduce(g.to(DEV), s.to(DEV), to_dev(bn))

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from mimic_amd import ops as real_ops
 from mimic_amd.ops import Bn, Geom, Mask, RES_A, RES_B
 
-OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_bwd_reduce", "block_out_bwd",
+OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_relu_apply", "bn_bwd_reduce", "block_out_bwd",
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
@@ -189,6 +189,12 @@ def block_out_fwd(s, m, bn_s, a=RES_A, b=RES_B, out_stats=None):
     out, stored = _store(a * (s * scale + shift) + b * m, dt)
     _accum(out_stats, out)
     return stored
+
+
+def bn_relu_apply(x, bn):
+    dt = x.dtype
+    _, _, scale, shift = bn_coef(bn)
+    return _store(torch.relu(_f(x) * scale + shift), dt)[1]
 
 
 def bn_bwd_reduce(g, s, bn_s, sums=None):
