@@ -316,9 +316,8 @@ def main():
         all_by = sum(v[3] for v in prof.values())
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-            pmc_file = os.path.join(REPO, "profiles", f"latest_pmc_hbm_{args.config}.json")
-            if not os.path.exists(pmc_file):
-                pmc_file = os.path.join(REPO, "profiles", "latest_pmc_hbm.json")   # (config c2)
+            # (a file per config: another config's launches of the same instantiation are other layers -- no file, no figure)
+            pmc_file = os.path.join(REPO, "profiles", "latest_pmc_hbm.json" if args.config == "c2" else f"latest_pmc_hbm_{args.config}.json")
             with open(pmc_file) as f:
                 pm = json.load(f)["kernels"]
             hit = pm.get(name)
