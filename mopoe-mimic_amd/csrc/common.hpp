@@ -42,7 +42,11 @@ __device__ __forceinline__ float mask_at(const mopoe_mask_ref& m, long row, int 
   return m.mask[row * (long)C + c];
 }
 
+#ifdef MOPOE_DBG_NO_STAT_ATOMICS   // timing experiment only (A/B library; statistics are then wrong): DESIGN section 4, glue kernels
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { if (v == 1.2345e300) *p = v; }
+#else
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+#endif
 
 // ---- bf16 storage (BASELINE configs #3, #5): activations / activation gradients / MFMA operands are bfloat16 in HBM,
 // every sum stays fp32 (statistics fp64).  A bf16 value is the upper half of the fp32 with the same value; rounding to
