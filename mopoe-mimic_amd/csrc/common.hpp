@@ -20,6 +20,10 @@ struct BnC {
 
 __device__ __forceinline__ BnC bn_coef(const mopoe_bn_ref& b, int c) {
   BnC r;
+#ifdef MOPOE_DBG_CONST_COEF   // timing experiment only (A/B library, wrong results): what the coefficient prologues cost
+  r.mean = 0.f; r.rstd = 1.f; r.scale = 1.f; r.shift = 0.f;
+  return r;
+#endif
   if (b.mode == 1) {
     const double m = b.sums[c] * b.inv_count;
     double v = b.sums[b.C + c] * b.inv_count - m * m;
