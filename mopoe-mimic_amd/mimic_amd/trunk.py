@@ -155,19 +155,14 @@ class StatsArena:
 
 # MOPOE_MATERIALIZE: whether the second conv of a block takes relu(bn2(d1)) written out once by ops.bn_relu_apply (the conv and
 # its weight gradient then run their plain-operand forms: all-DMA, deeper pipelines) instead of applying it on the operand
-# load.  "auto" (default): in the bf16 family, where the on-load forms lose most (measured, 1 x MI355X: C3 20 488 -> 21 036
-# samples/s, C5 4 745 -> 4 860; fp32 C2 5 616 vs 5 608-5 642, i.e. nothing: left on load there); "1" always, "0" never.
-# Doing the same for conv1's operand costs more than it gives (C3 20 677, C5 4 770: its input is the block's big input and
-# the 1x1 conv is HBM-bound already).
-MATERIALIZE = os.environ.get("MOPOE_MATERIALIZE", "auto")
+# load.  "1" (default): always -- measured on 1 x MI355X: bf16 C3 20 488 -> 21 036 samples/s, C5 4 745 -> 4 860; fp32 C2 +0.5 % in
+# three same-box A/B runs (5 616 -> 5 642, 5 554-5 565 -> 5 589-5 592); "0": on load.  Doing the same for conv1's operand costs
+# more than it gives (C3 20 677, C5 4 770: its input is the block's big input and the 1x1 conv is HBM-bound already).
+MATERIALIZE = os.environ.get("MOPOE_MATERIALIZE", "1")
 
 
 def _materialize(g2, d1) -> bool:
-    if MATERIALIZE == "0":
-        return False
-    if MATERIALIZE == "1":
-        return True
-    return d1.dtype in (torch.bfloat16, torch.float16)
+    return MATERIALIZE != "0"
 
 
 def _master_weight(mod):
