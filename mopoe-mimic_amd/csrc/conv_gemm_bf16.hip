@@ -792,11 +792,21 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   // per stage).  Default: the LDS-DMA form (MOPOE_BF16_NO_GLDS = the register-staged one).
   static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");
   const bool glds = plan && plan->tile >= 0 ? plan->tile >= 5 : glds_default;
-  if (plan && plan->tile > 6) { set_error("bf16 wgrad plan: tile %d (0, 2, 5, 6)", plan->tile); return MOPOE_ERR_ARG; }
+  // tile 7: the 128 tile on LDS-DMA with TWO taps per block on the side of the gathered operand when that side has 64 channels
+  // (conv_gemm_bf16_glds.inc, MERGE): convs with Cin = 64 (1), transposed convs with Cout = 64 (2); plain operands, even tap count
+  const bool xf_ = a.bn_in.mode != 0;
+  const int merge_ok = (!xf_ && taps % 2 == 0) ? (a.x_is_big ? (g->Cin == 64 ? 1 : 0) : (g->Cout == 64 ? 2 : 0)) : 0;
+  if (plan && plan->tile > 7) { set_error("bf16 wgrad plan: tile %d (0, 2, 5, 6, 7)", plan->tile); return MOPOE_ERR_ARG; }
+  if (plan && plan->tile == 7 && !merge_ok) {
+    set_error("bf16 wgrad plan: tile 7 (two taps per block) needs a plain operand, an even tap count and 64 channels on the gathered side");
+    return MOPOE_ERR_ARG;
+  }
+  const int merge = plan && plan->tile == 7 ? merge_ok : 0;
+  if (merge) big = true;
   const int T = big ? 128 : 64;
-  const int nI = ceil_div(g->Cin, T), nJ = ceil_div(g->Cout, T);
+  const int nI = merge == 1 ? 1 : ceil_div(g->Cin, T), nJ = merge == 2 ? 1 : ceil_div(g->Cout, T);
   a.nJ = nJ;
-  const long tiles = (long)nI * nJ * taps;
+  const long tiles = (long)nI * nJ * (merge ? taps / 2 : taps);
   long split = (1024 + tiles - 1) / tiles;
   if (plan && plan->split > 0) split = plan->split;
   const int kp = glds ? 64 : BKH;                 // pixels per chunk
@@ -817,7 +827,14 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   const bool xf = a.bn_in.mode != 0;
   ProfScope prof(stream, flops, (glds ? PROF_BF16_WGRAD_GLDS : PROF_BF16_WGRAD) + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
-  dim3 grid(nI * nJ, taps, (unsigned)split);
+  dim3 grid(nI * nJ, merge ? taps / 2 : taps, (unsigned)split);
+  if (merge) {
+    if (merge == 1 && pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<128, false, true, 1>), grid, dim3(256), 0, stream, a);
+    else if (merge == 1) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<128, false, false, 1>), grid, dim3(256), 0, stream, a);
+    else if (pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<128, false, true, 2>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<128, false, false, 2>), grid, dim3(256), 0, stream, a);
+    return check_launch("wgrad_gemm_bf16_glds (two taps per block)");
+  }
   if (glds) {
 #define MOPOE_LAUNCH_WG(T_)                                                                                             \
   do {                                                                                                                 \

@@ -344,11 +344,20 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = 
     return cands
 
 
-def _wgrad_candidates(g: Geom, bf16: bool = False):
+def _wgrad_candidates(g: Geom, bf16: bool = False, plain_operand: bool = False):
     if min(g.Cin, g.Cout) == 1:
         return {}
     ms = g.N * g.Hs * g.Ws
     cands = {}
+    # tile 7 (bf16, plain operand): two taps per block on the gathered operand's side when that side has 64 channels
+    if bf16 and BF16_GLDS and plain_operand and g.taps % 2 == 0 and (g.Cout if g.transposed else g.Cin) == 64:
+        tiles = -(-(g.Cin if g.transposed else g.Cout) // 128) * (g.taps // 2)
+        seen = set()
+        for target in (256, 512, 768, 1024, 1536, 2048, 4096):
+            s = max(1, min(-(-target // tiles), -(-ms // 128)))
+            if s not in seen:
+                seen.add(s)
+                cands[(7, s)] = min(1.0, tiles * s / 768)
     # tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_glds.inc, conv_gemm_bf16_glds.inc)
     glds = (BF16_GLDS if bf16 else F32_GLDS and g.Cin % 4 == 0 and g.Cout % 4 == 0)
     for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))):
@@ -605,7 +614,8 @@ def conv_wgrad(x, dy, g: Geom, bn_in: Optional[Bn] = None, out=None):
     def launch(plan, dst, is_zero):
         _check(fn(_p(x), _p(dy), _p(dst), C.byref(gc), bnr, C.c_int32(is_zero), plan, stream))
 
-    plan = _tuned_plan(key, lambda: _wgrad_candidates(g, bf16=key[0] == "wgrad16"), lambda ref: launch(ref, _scratch_like(dwp), 1))
+    plan = _tuned_plan(key, lambda: _wgrad_candidates(g, bf16=key[0] == "wgrad16", plain_operand=bn_in is None),
+                       lambda ref: launch(ref, _scratch_like(dwp), 1))
     launch(plan, dwp, int(out is not None))
     return dwp
 

@@ -154,6 +154,38 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
                       TB.conv_wgrad(x, dy, g, bn_in=bn), rtol=2e-3, atol_rel=1e-3)
 
 
+MERGE_GEOMS = [
+    ("enc_64to128_b9", Geom(9, 8, 8, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1, False)),            # convs: Cin = 64, rows of the tile = (tap, ci)
+    ("enc_64to192_odd_grid", Geom(3, 6, 5, 12, 10, 64, 192, 4, 4, 2, 2, 1, 1, False)),      # partial column tile, no power-of-two map
+    ("enc_64to64_k4", Geom(2, 8, 8, 16, 16, 64, 64, 4, 4, 2, 2, 1, 1, False)),              # half of the columns empty
+    ("dec_128to64_b5", Geom(5, 8, 8, 16, 16, 128, 64, 4, 4, 2, 2, 1, 1, True)),             # transposed: Cout = 64, columns = (tap, co)
+    ("dec_64to64_b3", Geom(3, 16, 16, 32, 32, 64, 64, 4, 4, 2, 2, 1, 1, True)),             # half of the rows empty
+    ("dec_192to64_odd_grid", Geom(2, 5, 6, 10, 12, 192, 64, 4, 4, 2, 2, 1, 1, True)),       # partial row tile
+    ("text_convT1d_64", Geom(4, 1, 16, 1, 32, 128, 64, 1, 4, 1, 2, 0, 1, True)),            # 1-D, four taps
+]
+
+
+@pytest.mark.parametrize("name,g", MERGE_GEOMS, ids=[n for n, _ in MERGE_GEOMS])
+def test_wgrad_two_taps_per_block_bf16(name, g: Geom):
+    """wgrad tile 7: two taps per block on the side of the gathered operand (64 channels there) -- the (tap, channel) rows /
+    columns of its 128 x 128 tile against the emulation, with and without a split of the pixel reduction; refused with BN on
+    load and where the gathered side has another channel count"""
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(g.in_shape, generator=gen).to(BF)
+    dy = torch.randn(g.out_shape, generator=gen).to(BF)
+    ref = TB.conv_wgrad(x, dy, g)
+    for split in (1, 2, 5):
+        with ops.force_plan(7, split):
+            check(f"{name}/wgrad_t7s{split}", ops.conv_wgrad(x.to(DEV), dy.to(DEV), g), ref, rtol=3e-4, atol_rel=3e-4)
+    with ops.force_plan(7, 1):
+        bn = make_bn(g.Cin, x.numel() // g.Cin, 1, gen, x.float())
+        with pytest.raises(ops.MopoeHipError):
+            ops.conv_wgrad(x.to(DEV), dy.to(DEV), g, bn_in=to_dev(bn))
+        g2 = Geom(2, 4, 4, 8, 8, 128, 128, 4, 4, 2, 2, 1, 1, False)
+        with pytest.raises(ops.MopoeHipError):
+            ops.conv_wgrad(torch.zeros(g2.in_shape, dtype=BF, device=DEV), torch.zeros(g2.out_shape, dtype=BF, device=DEV), g2)
+
+
 def _glds_case(name, g: Geom):
     """the ops the LDS-DMA tiles serve (csrc/conv_gemm_bf16_glds.inc): forward convs whose operand needs no BN on load
     (plain, fp32 result, bias + element mask, bias + statistics = a projection shortcut) and every form of the input gradient"""

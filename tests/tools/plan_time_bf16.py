@@ -45,3 +45,23 @@ for name, g in layers.items():
             us = e0.elapsed_time(e1) / 10 * 1e3
             row.append(f"t{tile}:{us:6.1f}us/{fl(g, kind) / us / 1e6:4.0f}TF")
         print(f"{name:18s} {kind:6s} " + "  ".join(row), flush=True)
+    if "wgrad" in os.environ.get("KINDS", "").split(","):     # weight gradient, plain operand: tiles 2 / 6 (64), 0 / 5 (128), 7 (two taps per block)
+        row = []
+        for tile in (2, 6, 0, 5, 7):
+            if tile in (0, 5) and min(g.Cin, g.Cout) <= 64:
+                continue
+            if tile == 7 and (g.Cout if g.transposed else g.Cin) != 64:
+                continue
+            best = None
+            for split in (16, 32, 64, 128):
+                with ops.force_plan(tile, split):
+                    for _ in range(3): ops.conv_wgrad(x, dy, g)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10): ops.conv_wgrad(x, dy, g)
+                    e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / 10 * 1e3
+                if best is None or us < best[0]:
+                    best = (us, split)
+            row.append(f"t{tile}:{best[0]:6.1f}us/{fl(g, 'fwd') / best[0] / 1e6:4.0f}TF s{best[1]}")
+        print(f"{name:18s} wgrad  " + "  ".join(row), flush=True)
