@@ -826,7 +826,8 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   }
   const double flops = 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps;
   const bool xf = a.bn_in.mode != 0;
-  ProfScope prof(stream, flops, (glds ? PROF_BF16_WGRAD_GLDS : PROF_BF16_WGRAD) + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
+  ProfScope prof(stream, flops, merge ? PROF_BF16_WGRAD_GLDS_MERGE + merge - 1
+                                      : (glds ? PROF_BF16_WGRAD_GLDS : PROF_BF16_WGRAD) + (big ? 0 : 2) + (xf ? 1 : 0), (double)xb + (double)db);
   dim3 grid(nI * nJ, merge ? taps / 2 : taps, (unsigned)split);
   if (merge) {
     if (merge == 1 && pow2) hipLaunchKernelGGL((wgrad_gemm_bf16_glds_kernel<128, false, true, 1>), grid, dim3(256), 0, stream, a);

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -958,7 +958,9 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 120
+    names = [None] * 122
+    for m in (1, 2):
+        names[120 + m - 1] = f"wgrad_gemm_bf16_glds_kernel<128, false, true, {m}>"
     for i, (tt, st) in enumerate((("128", (2, 2)), ("64", (4, 2)))):
         for xf in (0, 1):
             names[116 + 2 * i + xf] = f"wgrad_gemm_f32_glds_kernel<{tt}, {'true' if xf else 'false'}, {st[xf]}>"
@@ -967,9 +969,10 @@ def _prof_kind_names():
             names[104 + 3 * i + spec - 1] = f"gather_gemm_f32_glds_kernel<{tt.format(spec)}>"
     for i, tt in enumerate(("128", "64")):
         for xf in (0, 1):
-            names[100 + 2 * i + xf] = f"wgrad_gemm_bf16_glds_kernel<{tt}, {'true' if xf else 'false'}, true>"
+            names[100 + 2 * i + xf] = f"wgrad_gemm_bf16_glds_kernel<{tt}, {'true' if xf else 'false'}, true, 0>"
     for i, tt in enumerate(("128, 128, 2, 2, 2, 2", "256, 128, 4, 2, 2, 2", "128, 64, 4, 1, 2, 2")):
         names[94 + i] = f"gather_gemm_bf16_glds_kernel<{tt}>"
+    names[98] = "gather_gemm_bf16_glds_kernel<64, 64, 2, 2, 2, 4>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 128, 2, 2, {}, 3", "256, 128, 4, 2, {}, 2", "256, 128, 4, 2, {}, 3",
                             "128, 64, 4, 1, {}, 2", "128, 64, 4, 1, {}, 3", "64, 64, 2, 2, {}, 4")):
         for k, spec in enumerate((1, 3)):
