@@ -243,7 +243,7 @@ class _Plan(C.Structure):
 # kept for the life of the process.  All plans compute the same sums (in a different association order).
 # MOPOE_AUTOTUNE=0 keeps the static heuristic (plan = NULL).
 AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") != "0"
-_TUNE_REPS = 3
+_TUNE_REPS = int(os.environ.get("MOPOE_TUNE_REPS", "3"))
 # Optional: leave the first N conv launches of the process on the static heuristic and start tuning afterwards
 # (a GPU that has just left idle ranks candidates differently from steady state).  Default 0 = tune at first use,
 # so that one warm-up step settles every plan.
@@ -262,6 +262,37 @@ _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128)
 
 
 _forced_plan = None
+
+# Committed launch plans: the tuner's choices for the BASELINE configurations, measured on an MI355X
+# by tests/tools/make_plan_table.py and kept in mimic_amd/plans_gfx950.json.  A triple found in the table takes its plan
+# from it; the tuner only runs for triples the table does not hold (other shapes / batch sizes), or for everything under
+# MOPOE_AUTOTUNE=force.  Two processes therefore launch the same kernels, and a bench set-up does not spend its first
+# step timing ~30 candidates per layer.
+PLAN_TABLE_PATH = os.environ.get("MOPOE_PLAN_TABLE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans_gfx950.json"))
+USE_PLAN_TABLE = os.environ.get("MOPOE_AUTOTUNE", "1") != "force" and os.environ.get("MOPOE_PLAN_TABLE", "") != "0"
+_plan_table = None
+
+
+def plan_key_str(key) -> str:
+    """the table's key: op name, the 14 geometry numbers, the fusion flags"""
+    g = key[1]
+    geo = ",".join(str(int(getattr(g, f))) for f in ("N", "Hs", "Ws", "Hb", "Wb", "Cin", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "transposed"))
+    return f"{key[0]}|{geo}|" + ",".join(str(int(f)) if isinstance(f, bool) else str(f) for f in key[2:])
+
+
+def _table_plan(key):
+    """(found, plan or None) from the committed table"""
+    global _plan_table
+    if _plan_table is None:
+        _plan_table = {}
+        if USE_PLAN_TABLE and os.path.exists(PLAN_TABLE_PATH):
+            import json
+            with open(PLAN_TABLE_PATH) as f:
+                _plan_table = json.load(f).get("plans", {})
+    v = _plan_table.get(plan_key_str(key), False)
+    if v is False:
+        return False, None
+    return True, (None if v is None else _Plan(int(v[0]), int(v[1])))
 
 
 def clear_plans():
@@ -393,7 +424,13 @@ def _tuned_plan(key, cands_fn, launch):
     if key in _plans:
         p = _plans[key]
         return None if p is None else C.byref(p)
-    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+    if not AUTOTUNE:
+        return None
+    found, p = _table_plan(key)
+    if found:
+        _plans[key] = p
+        return None if p is None else C.byref(p)
+    if torch.cuda.is_current_stream_capturing():
         return None
     global _conv_calls
     _conv_calls += 1

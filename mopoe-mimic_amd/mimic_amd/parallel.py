@@ -61,14 +61,32 @@ class GradAllReducer:
             if net is not None and getattr(net, "_grad_reducer", None) is self:
                 net._grad_reducer = None
 
+    def _broadcast_flat(self, tensors, src: int, bucket_bytes: int = 256 << 20):
+        """broadcast many tensors as a few flat messages (one per dtype and <= bucket_bytes): 397 parameters + 306 buffers
+        are 3-4 collectives instead of 703 (round 3 issued one per tensor)"""
+        groups = {}
+        for t in tensors:
+            groups.setdefault(t.dtype, []).append(t)
+        with torch.no_grad():
+            for dtype, ts in groups.items():
+                i = 0
+                while i < len(ts):
+                    j, nbytes = i, 0
+                    while j < len(ts) and (j == i or nbytes + ts[j].numel() * ts[j].element_size() <= bucket_bytes):
+                        nbytes += ts[j].numel() * ts[j].element_size()
+                        j += 1
+                    flat = torch.cat([t.detach().reshape(-1) for t in ts[i:j]])
+                    dist.broadcast(flat, src, async_op=True).wait()
+                    off = 0
+                    for t in ts[i:j]:
+                        t.detach().copy_(flat[off:off + t.numel()].view_as(t))
+                        off += t.numel()
+                    i = j
+
     def broadcast_parameters(self, src: int = 0):
         if not self.active:
             return
-        with torch.no_grad():
-            works = [dist.broadcast(t, src, async_op=True)
-                     for t in list(self.module.parameters()) + list(self.module.buffers())]
-            for w in works:
-                w.wait()
+        self._broadcast_flat(list(self.module.parameters()) + list(self.module.buffers()), src)
         # a broadcast writes the tensors without bumping their version counters: derived copies (bf16 weight shadows,
         # the padded vocabulary head) must not trust the counters across it
         from .layout import note_params_changed
@@ -90,9 +108,7 @@ class GradAllReducer:
     def sync_buffers(self, src: int = 0):
         if not self.active:
             return
-        works = [dist.broadcast(b, src, async_op=True) for b in self.module.buffers()]
-        for w in works:
-            w.wait()
+        self._broadcast_flat(list(self.module.buffers()), src)
 
     def _launch(self, t: torch.Tensor):
         op = self._avg if self._avg is not None else dist.ReduceOp.SUM

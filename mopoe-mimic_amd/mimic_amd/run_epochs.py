@@ -316,28 +316,41 @@ class _StepRunner:
         batch_d = {k: v.to(self.exp.flags.device, non_blocking=True) for k, v in batch[0].items()}
         sig = _batch_signature(batch_d)
         if self.graphed is None and self.graph_allowed() and sig[0][1][0] == self.exp.flags.batch_size:
-            progress, err = {"eager_steps": 0}, None
+            progress, err, oom = {"eager_steps": 0}, None, None
             try:
                 # (its set-up runs eager steps on this batch: they are ordinary optimiser steps of the epoch)
                 self.graphed = GraphedTrainStep(self.exp, (batch_d, None), self.pack, self.reducer, warmup=1, progress=progress)
             except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
-                if isinstance(e, torch.cuda.OutOfMemoryError) or str(e).startswith(("HIP out of memory", "CUDA out of memory")):
-                    raise
                 self.graphed, err = None, e
+                if isinstance(e, torch.cuda.OutOfMemoryError) or str(e).startswith(("HIP out of memory", "CUDA out of memory")):
+                    oom = e
             # data parallel: graphed and eager ranks issue their collectives at different points of the step, so the ranks
-            # agree on ONE form (all of them drop to the eager step if any rank's capture failed)
+            # agree on ONE form (all of them drop to the eager step if any rank's capture failed).  An out-of-memory rank
+            # takes part in the agreement before it re-raises: its peers must not be left waiting in the collective.
             ok = self.graphed is not None
-            if self.reducer is not None and self.reducer.active:
+            dp = self.reducer is not None and self.reducer.active
+            if dp:
                 ok = self.reducer.all_agree(ok)
+            if oom is not None:
+                raise oom
             if not ok:
                 self.failed, self.graphed = True, None
                 why = f"{type(err).__name__}: {err}" if err is not None else "another rank's capture failed"
                 warnings.warn(f"hipGraph capture of the train step failed ({why}); running eager steps")
             else:
                 self.signature = sig
-            if progress["eager_steps"] > 0:
-                # the set-up has already trained on this batch (optimiser step and, data parallel, its collectives
-                # included): running it again would train twice on it and, on one rank only, unpair every later collective
+            # Has the set-up already trained on this batch (optimiser step and, data parallel, its collectives included)?
+            # Running it again would train twice on it.  Data parallel, the answer must be the SAME on every rank -- a rank
+            # whose set-up failed before its eager step completed would otherwise issue a step's collectives its peers never
+            # pair -- so the ranks compare notes and stop together if they differ.
+            consumed = progress["eager_steps"] > 0
+            if dp:
+                all_did = self.reducer.all_agree(consumed)          # (both reductions on every rank, whatever they answer)
+                none_did = self.reducer.all_agree(not consumed)
+            if dp and not (all_did or none_did):
+                raise RuntimeError("data-parallel set-up: the ranks disagree on whether the capture's warm-up step has "
+                                   "trained on the first batch; every later collective would be unpaired")
+            if consumed:
                 self.n_eager += 1
                 return
         if self.graphed is not None and sig == self.signature:

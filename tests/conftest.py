@@ -24,7 +24,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the GPU suite (round 3's was alphabetical by file and was cut off by the driver's 900 s limit before it reached
+# the reference goldens): first the tests that compare the HIP path with vectors the REFERENCE ITSELF produced (G0-G5, the
+# train step / checkpoint / estimator / input-pipeline rows of SURVEY 8f), then data parallelism + launcher + bench contract,
+# then the full-size G7 fixtures, then the per-kernel tests, last the tests that still run a live CPU oracle.
+_ORDER = [
+    ("test_model_gpu.py::test_g0_", 0), ("test_model_gpu.py::test_g1_", 0), ("test_model_gpu.py::test_g3_", 0),
+    ("test_model_gpu.py::test_graphed_train_step", 0), ("test_model_gpu.py::test_partial_modalities", 0),
+    ("test_model_gpu.py::test_cond_generation", 0), ("test_model_gpu.py::test_checkpoint", 0),
+    ("test_model_gpu.py::test_likelihood_estimator", 0), ("test_model_gpu.py::test_g5_", 0),
+    ("test_model_gpu.py::test_char_encoding", 0), ("test_model_gpu.py::test_input_pipeline", 0),
+    ("test_model_gpu.py::test_missing_library", 0), ("test_model_gpu.py::test_train_mode_random_dropout", 0),
+    ("test_launcher_gpu.py", 1), ("test_dp_", 1), ("test_bench_gpu.py", 1),
+    ("test_model_gpu.py::test_c2_full_size", 2), ("test_bf16_gpu.py::test_c3_full_size", 2),
+    ("test_bf16_gpu.py::test_c5_full_size", 2), ("test_bf16_gpu.py::test_bf16_trajectory", 2),
+    ("test_model_gpu.py::test_c", 3), ("test_bf16_gpu.py::test_graphed", 3),
+    ("test_hip_ops_gpu.py", 4), ("test_bf16_gpu.py", 5), ("test_model_gpu.py", 6),
+]
+
+
+def _priority(nodeid):
+    for key, prio in _ORDER:
+        if key in nodeid:
+            return prio
+    return 4
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: _priority(it.nodeid))      # (stable: the file order is kept inside a class)
     # GPU tests are skipped (not failed) when no device is present and they were not deselected.
     try:
         import torch

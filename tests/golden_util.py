@@ -81,3 +81,109 @@ def make_mimic_files(dir_data, img_size=16, n_train=40, n_eval=12, seed=3):
         pd.DataFrame(lab, columns=["Lung Opacity", "Pleural Effusion", "Support Devices"]).to_csv(
             os.path.join(d, f"{split}_labels.csv"), index=False)
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G7: compact fixtures of FULL-SIZE gradients (oracle/gen_g7.py writes them in the build container; the GPU tests read
+# them instead of running CPU backward passes of 65-150 M-parameter models on the GPU box's host cores).
+#
+# A gradient tensor t of n elements is kept as
+#   * n <= EXACT_MAX: every element (float32);
+#   * otherwise: ||t||_2 and max|t| (float64), a COUNT SKETCH  S t  (SKETCH_M signed bucket sums: element i goes to
+#     bucket i mod SKETCH_M with a seeded random sign) and SAMPLE_N seeded random elements.
+# For any tensor a, E ||S a - S t||^2 = ||a - t||^2 over the draw of the signs (whatever the partition), with relative
+# standard deviation sqrt(2 / SKETCH_M) = 8.8 %: the relative L2 error of a whole tensor -- including an error confined to
+# one row, which a sample misses -- is read from the sketch; element-wise statistics (quantiles of |a - t|, the L2 error
+# with the largest 1 % set aside) from the sample.  Signs and sample positions are functions of n alone.
+# ---------------------------------------------------------------------------------------------------------------
+EXACT_MAX, SKETCH_M, SAMPLE_N = 1024, 256, 512
+_PLANS = {}
+
+
+def sketch_plan(n):
+    if n not in _PLANS:
+        gen = torch.Generator().manual_seed(0x5EED0000 + n % 1000003)
+        signs = (torch.randint(0, 2, (n,), generator=gen, dtype=torch.int8) * 2 - 1)
+        sample = torch.randperm(n, generator=gen)[:SAMPLE_N].sort().values
+        _PLANS[n] = (signs, sample)
+        if len(_PLANS) > 64:
+            _PLANS.pop(next(iter(_PLANS)))
+    return _PLANS[n]
+
+
+def sketch_of(t):
+    """(sketch [SKETCH_M] float64, sample [SAMPLE_N] float64) of a tensor with more than EXACT_MAX elements"""
+    t = t.detach().double().cpu().flatten()
+    signs, sample = sketch_plan(t.numel())
+    v = t * signs
+    pad = (-v.numel()) % SKETCH_M
+    if pad:
+        v = torch.cat([v, v.new_zeros(pad)])
+    return v.view(-1, SKETCH_M).sum(0), t[sample]
+
+
+def pack_grad(store, prefix, t):
+    """write tensor t's fixture entries under `prefix`"""
+    t = t.detach().double().cpu().flatten()
+    if t.numel() <= EXACT_MAX:
+        store[prefix + "/x"] = t.float().numpy()
+        return
+    sk, sa = sketch_of(t)
+    store[prefix + "/n"] = np.array([t.norm().item(), t.abs().max().item()])
+    store[prefix + "/sk"] = sk.float().numpy()
+    store[prefix + "/sa"] = sa.float().numpy()
+
+
+class PackedGrad:
+    """one gradient tensor of a G7 fixture, with the comparisons the parity tests need"""
+
+    def __init__(self, g, prefix, numel):
+        self.numel = numel
+        if prefix + "/x" in g.files:
+            self.exact = torch.from_numpy(g[prefix + "/x"]).double()
+            self.norm, self.absmax = self.exact.norm().item(), (self.exact.abs().max().item() if numel else 0.0)
+        else:
+            self.exact = None
+            self.norm, self.absmax = (float(v) for v in g[prefix + "/n"])
+            self.sk = torch.from_numpy(g[prefix + "/sk"]).double()
+            self.sa = torch.from_numpy(g[prefix + "/sa"]).double()
+
+    def diff(self, got):
+        """(estimate of ||got - t||_2, element errors |got - t| on the sample or on every element, ||got||_2)"""
+        a = got.detach().double().cpu().flatten()
+        assert a.numel() == self.numel, (a.numel(), self.numel)
+        if self.exact is not None:
+            d = (a - self.exact)
+            return d.norm().item(), d.abs(), a.norm().item()
+        sk, sa = sketch_of(a)
+        return (sk - self.sk).norm().item(), (sa - self.sa).abs(), a.norm().item()
+
+    def sample_scale(self):
+        """sqrt(n / sample size): turns an L2 norm over the sample into an estimate of the norm over the tensor"""
+        return 1.0 if self.exact is not None else (self.numel / SAMPLE_N) ** 0.5
+
+
+def pack_bits(t):
+    """a {0, 2}-valued dropout multiplier tensor as packed bits"""
+    return np.packbits((t != 0).flatten().numpy().astype(np.uint8))
+
+
+def unpack_mask(bits, shape):
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(bits)[:n].astype(np.float32) * 2.0).view(*shape)
+
+
+def weights_fingerprint(sd):
+    """a few numbers that identify a seeded state dict (the fixtures' weights are regenerated from their seed on the GPU box:
+    a different torch CPU generator there would otherwise show up as a parity failure of the kernels)"""
+    keys = sorted(k for k, v in sd.items() if v.is_floating_point())
+    pick = keys[:: max(1, len(keys) // 12)]
+    return np.array([sd[k].double().abs().sum().item() for k in pick])
+
+
+REC_SAMPLES = 16384
+
+
+def rec_sample_index(numel):
+    """positions of the reconstruction pixels a G7 fixture keeps"""
+    return torch.randperm(numel, generator=torch.Generator().manual_seed(numel % 1000003))[:REC_SAMPLES].sort().values

@@ -44,3 +44,34 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp")):
                 text = open(os.path.join(root, f)).read()
                 assert "mopoe_ref" not in text and "torch_backend" not in text, os.path.join(root, f)
+
+
+def test_every_collective_is_asynchronous():
+    """mimic_amd.parallel's rule (DESIGN section 6): a SYNCHRONOUS collective records its completion event on the caller's
+    stream, the process group's watchdog queries it while run_epochs.GraphedTrainStep is capturing that stream, and the
+    HIP runtime answers with hipErrorCapturedEvent (capture invalidated, process aborted).  So every torch.distributed
+    collective in the product package and in bench.py must carry async_op=True (and dist.barrier, which has no such form
+    on the caller's stream, must not appear at all)."""
+    import ast
+    names = {"all_reduce", "broadcast", "all_gather", "all_gather_into_tensor", "reduce", "reduce_scatter",
+             "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "gather", "scatter", "send", "recv", "barrier",
+             "monitored_barrier", "broadcast_object_list", "all_gather_object"}
+    files = [os.path.join(REPO, "bench.py")]
+    for root, _dirs, fs in os.walk(os.path.join(REPO, "mopoe-mimic_amd", "mimic_amd")):
+        files += [os.path.join(root, f) for f in fs if f.endswith(".py")]
+    seen, bad = 0, []
+    for path in files:
+        for node in ast.walk(ast.parse(open(path).read(), path)):
+            if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in names):
+                continue
+            base = node.func.value
+            if not (isinstance(base, ast.Name) and base.id == "dist"
+                    or isinstance(base, ast.Attribute) and base.attr == "distributed"):
+                continue
+            seen += 1
+            is_async = any(kw.arg == "async_op" and isinstance(kw.value, ast.Constant) and kw.value.value is True
+                           for kw in node.keywords)
+            if node.func.attr in ("barrier", "monitored_barrier", "broadcast_object_list", "all_gather_object") or not is_async:
+                bad.append(f"{os.path.relpath(path, REPO)}:{node.lineno} dist.{node.func.attr}")
+    assert seen >= 5, seen
+    assert not bad, bad

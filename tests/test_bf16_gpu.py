@@ -20,6 +20,8 @@ import torch
 import mopoe_ref as R
 import torch_backend as TB
 from model_util import build_exp
+from golden_util import load, cfg_from, weights_fingerprint
+from g7_util import check_bf16_case, g7_inputs
 from mimic_amd import ops, run_epochs as RE
 from mimic_amd.ops import Bn, Geom, Mask
 from test_hip_ops_gpu import check, make_bn, to_dev
@@ -477,54 +479,46 @@ def test_small_model_bf16_vs_oracle():
     _model_vs_oracle(cfg, 8, seed=73, tag="small_eval", mode="eval", grad_check=False)
 
 
-def test_c3_shape_bf16_vs_oracle_b16():
-    """BASELINE config #3's architecture (128 px, class_dim 128, DIM_img 64) at B = 16: every gradient against the oracle"""
-    cfg = R.Cfg(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=16)
-    _model_vs_oracle(cfg, 16, seed=81, tag="c3_b16")
-
-
 def test_c3_full_size_bf16():
-    """BASELINE config #3 exactly: 128 px, class_dim 128, B = 256, bf16 -- forward scalars against the oracle (bf16 mode
-    and fp32 arithmetic), EVERY parameter gradient against the bf16-mode oracle's backward (one CPU backward at B = 256),
-    then three Adam steps (finite gradients, decreasing loss)."""
-    cfg = R.Cfg(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=256)
-    exp = _model_vs_oracle(cfg, 256, seed=91, tag="c3_b256", grad_check=True)
+    """BASELINE config #3 exactly: 128 px, class_dim 128, B = 256, bf16 -- forward scalars against the bf16-mode oracle and
+    the REFERENCE's fp32 run, EVERY parameter gradient against both (fixture G7 c3_b256_bf16: the CPU passes at B = 256 ran
+    in the build container, oracle/gen_g7.py), then three Adam steps (finite gradients, decreasing loss)."""
+    exp, cfg, _ = check_bf16_case("c3_b256_bf16")
     _three_steps(exp, cfg, 256, seed=92)
 
 
-def test_c5_full_size_bf16():
-    """BASELINE config #5 exactly: 256 px (the stride-4 block), class_dim 256, B = 32, bf16: forward scalars and every
-    parameter gradient."""
-    cfg = R.Cfg(img_size=256, class_dim=256, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=32)
-    exp = _model_vs_oracle(cfg, 32, seed=95, tag="c5_b32", grad_check=True)
+def test_c5_full_size_bf16_and_fp32():
+    """BASELINE config #5 exactly: 256 px (the stride-4 block), class_dim 256, B = 32: the bf16 family's forward scalars and
+    every parameter gradient (fixture G7 c5_b32_bf16), and the fp32 family's forward scalars on the same inputs against the
+    reference's fp32 run (only B = 4 had run)."""
+    exp, cfg, g = check_bf16_case("c5_b32_bf16")
     _three_steps(exp, cfg, 32, seed=96)
-
-
-_TRAJ = {}
-
-
-def _fp32_oracle_trajectory(cfg, nrow, order, lr):
-    """losses of the fp32 CPU oracle over the Adam steps `order` (batch indices), computed once per test session"""
-    key = (cfg.img_size, cfg.class_dim, nrow, tuple(order), lr)
-    if key not in _TRAJ:
-        sd = R.init_state(cfg, seed=61)
-        batches = [R.synthetic_batch(cfg, nrow, seed=600 + i) for i in range(max(order) + 1)]
-        eps = batches[0][1]
-        leaf = R.leaf_state({k: v.clone() for k, v in sd.items()})
-        opt = torch.optim.Adam([v for v in leaf.values() if v.is_floating_point() and v.requires_grad], lr=lr)
-        losses = [R.adam_train_step(cfg, leaf, opt, batches[i][0], eps, R.Ctx("train_nodrop"))["total_loss"].item() for i in order]
-        _TRAJ[key] = (sd, batches, eps, losses)
-    return _TRAJ[key]
+    del exp
+    _, sd, batch, eps, _ = g7_inputs(g)
+    exp = build_exp(cfg, sd, "cuda", "train_nodrop", eps=eps)
+    got = RE.basic_routine_epoch(exp, ({k: v.cuda() for k, v in batch.items()}, None))
+    assert _rel(got["total_loss"].item(), float(g["fp32/total_loss"])) <= 1e-4
+    for k, v in got["klds"].items():
+        ref = float(g[f"fp32/klds/{k}"])
+        assert _rel(v.item(), ref) <= 1e-4 + 1e-6 / abs(ref), k
+    for k, v in got["log_probs"].items():
+        assert _rel(v.item(), float(g[f"fp32/log_probs/{k}"])) <= 1e-4, k
+    _three_steps(exp, cfg, 32, seed=99)
 
 
 @pytest.mark.parametrize("form", ["eager", "graph"])
-def test_bf16_trajectory_vs_fp32_oracle(form):
-    """ten Adam steps of the bf16 family at BASELINE config #3's architecture (B = 16) against the FP32 reference arithmetic
-    (oracle/mopoe_ref.py on the CPU), loss by loss at SURVEY 8c's bf16 tolerance (rtol 2e-2): the bf16 rounding points must
-    not bend the optimisation trajectory.  Both step forms: eager train_step and the captured hipGraph."""
-    cfg = R.Cfg(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=16)
-    order, lr = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8], 5e-5
-    sd, batches, eps, ref = _fp32_oracle_trajectory(cfg, 16, order, lr)
+def test_bf16_trajectory_vs_fp32_reference(form):
+    """ten Adam steps of the bf16 family at BASELINE config #3's architecture (B = 16) against the REFERENCE's own fp32
+    trajectory (fixture G7 traj_c3_b16: its module under torch.optim.Adam, run in the build container), loss by loss at
+    SURVEY 8c's bf16 tolerance (rtol 2e-2): the bf16 rounding points must not bend the optimisation trajectory.  Both step
+    forms: eager train_step and the captured hipGraph."""
+    g = load("g7_traj_c3_b16")
+    cfg = cfg_from(g["cfg"])
+    order, lr, ref = [int(i) for i in g["order"]], float(g["lr"]), [float(v) for v in g["losses"]]
+    sd = R.init_state(cfg, seed=int(g["seed_weights"]))
+    np.testing.assert_allclose(weights_fingerprint(sd), g["weights_fingerprint"], rtol=1e-12)
+    batches = [R.synthetic_batch(cfg, 16, seed=int(g["seed_batch0"]) + i) for i in range(max(order) + 1)]
+    eps = batches[0][1]
     exp = build_exp(cfg, {k: v.clone() for k, v in sd.items()}, "cuda", "train_nodrop", eps=eps, compute_dtype="bf16")
     exp.flags.initial_learning_rate = lr
     exp.set_optimizer(capturable=(form == "graph"))
@@ -541,29 +535,12 @@ def test_bf16_trajectory_vs_fp32_oracle(form):
         for i in order[2:]:
             step(dev(i))
             got.append(pack.read()["total_loss"])
-    for k, (g, r) in enumerate(zip(got, ref)):
-        if g is None:
+    for k, (gv, r) in enumerate(zip(got, ref)):
+        if gv is None:
             continue
-        _log(f"traj_{form} step {k}: hip_bf16={g:.6g} oracle_fp32={r:.6g} rel={_rel(g, r):.2e}")
-        assert _rel(g, r) <= 2e-2, (form, k, g, r)
+        _log(f"traj_{form} step {k}: hip_bf16={gv:.6g} reference_fp32={r:.6g} rel={_rel(gv, r):.2e}")
+        assert _rel(gv, r) <= 2e-2, (form, k, gv, r)
     assert ref[-1] < ref[0]      # (the trajectory moves: the comparison is not of ten copies of one number)
-
-
-def test_c5_full_size_fp32_properties():
-    """config #5's shape at full batch in fp32 (only B = 4 had run): forward scalars against the oracle."""
-    cfg = R.Cfg(img_size=256, class_dim=256, DIM_img=64, DIM_text=128, vocab_size=3517, batch_size=32)
-    sd = R.init_state(cfg, seed=97)
-    batch, eps = R.synthetic_batch(cfg, 32, seed=98)
-    with torch.no_grad():
-        ref = R.forward_step(cfg, sd, batch, eps, R.Ctx("train_nodrop"))
-    exp = build_exp(cfg, sd, "cuda", "train_nodrop", eps=eps)
-    got = RE.basic_routine_epoch(exp, ({k: v.cuda() for k, v in batch.items()}, None))
-    assert _rel(got["total_loss"].item(), ref["total_loss"].item()) <= 1e-4
-    for k, v in got["klds"].items():
-        assert _rel(v.item(), ref["klds"][k].item()) <= 1e-4 + 1e-6 / abs(ref["klds"][k].item()), k
-    for k, v in got["log_probs"].items():
-        assert _rel(v.item(), ref["log_probs"][k].item()) <= 1e-4, k
-    _three_steps(exp, cfg, 32, seed=99)
 
 
 def _three_steps(exp, cfg, nrow, seed):

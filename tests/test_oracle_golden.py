@@ -204,3 +204,62 @@ def test_g4_likelihood_estimator():
             for m_key in ("PA", "Lateral", "text", "joint"):
                 ref = float(g[f"{s_key}/{m_key}"])
                 assert abs(ll[m_key].item() - ref) <= 1e-5 * abs(ref) + 1e-4, (s_key, m_key, ll[m_key].item(), ref)
+
+
+def test_count_sketch_estimates_relative_l2():
+    """the G7 fixtures' compression (golden_util.pack_grad / PackedGrad): the count sketch's estimate of ||a - t|| is within
+    its stated noise of the truth, also when the error sits in ONE row of the tensor (which the random sample misses)"""
+    from golden_util import pack_grad, PackedGrad, SKETCH_M
+    gen = torch.Generator().manual_seed(0)
+    for shape, kind in (((320, 256, 16), "dense"), ((320, 256, 16), "one_row"), ((700,), "exact"), ((64, 1, 9), "exact")):
+        t = torch.randn(shape, generator=gen, dtype=torch.float64)
+        a = t.clone()
+        if kind == "one_row":
+            a[7] += 0.5 * torch.randn(a[7].shape, generator=gen, dtype=torch.float64)
+        else:
+            a += 0.02 * torch.randn(shape, generator=gen, dtype=torch.float64)
+        store = {}
+        pack_grad(store, "g/x", t)
+        class G(dict):
+            files = property(lambda self: list(self.keys()))
+        pg = PackedGrad(G(store), "g/x", t.numel())
+        est, elem, na = pg.diff(a)
+        true = (a - t).norm().item()
+        tol = 1e-6 if kind == "exact" else 5 * (2.0 / SKETCH_M) ** 0.5     # five standard deviations
+        assert abs(est - true) <= tol * true + 1e-6, (shape, kind, est, true)
+        assert abs(na - a.norm().item()) <= 1e-9 * na
+        assert abs(pg.norm - t.norm().item()) <= 1e-6 * pg.norm
+
+
+def test_g7_oracle_against_the_reference_at_config_2_shape():
+    """fixture G7 c2_b8 (the REFERENCE's fp32 / fp64 run at BASELINE config #2's architecture, B = 8: oracle/gen_g7.py): the
+    oracle's forward scalars and every parameter gradient against it -- the pin of oracle/mopoe_ref.py at the full
+    channel plan (G0 pins it on a 4-channel model); the larger G7 cases store the oracle's deviation from the reference
+    measured when they were generated, checked here too"""
+    from g7_util import g7_inputs
+    from golden_util import PackedGrad
+    g = load("g7_c2_b8")
+    cfg, sd, batch, eps, _ = g7_inputs(g)
+    leaf = R.leaf_state(sd)
+    out = R.forward_step(cfg, leaf, batch, eps, R.Ctx("train_nodrop"))
+    for k in ("total_loss",):
+        assert abs(out[k].item() - float(g[f"fp32/{k}"])) <= 1e-6 * abs(float(g[f"fp32/{k}"]))
+    for k, v in out["klds"].items():
+        assert abs(v.item() - float(g[f"fp32/klds/{k}"])) <= 1e-5 * abs(float(g[f"fp32/klds/{k}"])) + 1e-7
+    for k, v in out["log_probs"].items():
+        assert abs(v.item() - float(g[f"fp32/log_probs/{k}"])) <= 1e-6 * abs(float(g[f"fp32/log_probs/{k}"]))
+    out["total_loss"].backward()
+    worst = 0.0
+    for name, n, (scale, e_cpu, cpu_l2) in zip(g["grad_names"], g["grad_numel"], g["grad_meta"]):
+        name = str(name)
+        pg = PackedGrad(g, f"g/{name}", int(n))
+        l2, _elem, _ = pg.diff(leaf[name].grad)
+        rel = l2 / max(pg.norm, 1e-2 * scale * int(n) ** 0.5)
+        worst = max(worst, rel)
+        # the oracle (fp32) against the reference's fp64 gradient: as close as the reference's own fp32 run (cpu_l2), x3
+        assert rel <= max(2e-3, 3 * cpu_l2), (name, rel, cpu_l2)
+    for case in ("c2_b64", "c2_dimg128_b4", "c5_b4", "c3_b256_bf16", "c5_b32_bf16"):
+        dev_loss, dev_grad = load(f"g7_{case}")["oracle_vs_reference"]
+        assert dev_loss <= 1e-6 and dev_grad <= 1e-2, (case, dev_loss, dev_grad)
+    tr = load("g7_traj_c3_b16")
+    np.testing.assert_allclose(tr["oracle_losses"], tr["losses"], rtol=1e-5)
