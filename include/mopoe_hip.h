@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 14
+#define MOPOE_ABI_VERSION 15
 
 /* error codes */
 #define MOPOE_OK 0
@@ -275,6 +275,20 @@ int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, 
  * Replaces mopoe_token_nll_bwd (a memset + scatter of a [rows, V] tensor) followed by mopoe_logsoftmax_bwd. */
 int mopoe_token_softmax_grad(const float* logp, const float* ids, const float* g, int64_t rows, int32_t V, float norm,
                              void* dx, int32_t dx_is_bf16, void* stream);
+/* The vocabulary head WITHOUT a materialised log-softmax (reference word_encoding/DataGeneratorText.py:64-67,76-77: Conv1d k1
+ * -> LogSoftmax; mimic/modalities/MimicText.py:37-40: one_hot x log-probabilities; Modality.py:25-30).  The head GEMM writes
+ * the LOGITS [rows, V] once in the family's storage type (is_bf16: uint16 bf16 patterns, else float); V a multiple of 8
+ * (bf16) / 4 (fp32), rows 16-byte aligned (the padded head: pad columns carry a bias of -1e30).
+ *   mopoe_lse_rows:                   lse[r] = log sum_v exp(logits[r, v])                          (one pass over the logits)
+ *   mopoe_token_nll_logits_fwd:       out[0] = sum_r (lse[r] - logits[r, ids[r]]) / norm            (a gather)
+ *   mopoe_token_softmax_grad_logits:  dx[r, v] = g[0] / norm * (exp(logits[r, v] - lse[r]) - [v == ids[r]]), dx in the storage
+ *                                     type, may alias logits
+ * replace mopoe_logsoftmax_fwd + mopoe_token_nll_fwd + mopoe_token_softmax_grad on the training path. */
+int mopoe_lse_rows(const void* logits, int32_t is_bf16, int64_t rows, int32_t V, float* lse, void* stream);
+int mopoe_token_nll_logits_fwd(const void* logits, int32_t is_bf16, const float* lse, const float* ids, int64_t rows, int32_t V,
+                               float norm, float* out, double* ws, void* stream);
+int mopoe_token_softmax_grad_logits(const void* logits, int32_t is_bf16, const float* lse, const float* ids, const float* g,
+                                    int64_t rows, int32_t V, float norm, void* dx, void* stream);
 int mopoe_dense_logprob_rows(const float* logp, const float* target, int64_t rows, int64_t per_row,
                              int64_t target_rows, float* out, void* stream);
 
@@ -385,7 +399,7 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec
  *   60..74 gather_gemm_bf16_kernel: tile * 3 + (spec - 1)   (tiles 0..4 of the bf16 family)
  *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
-#define MOPOE_PROF_KINDS 122
+#define MOPOE_PROF_KINDS 124
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

@@ -1350,7 +1350,10 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   // plan tiles: 0 = 128x128, 2 = 64x64 (register-staged, 16 pixels per chunk); 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per
   // stage: conv_gemm_glds.inc; vector path only)
   if (plan && (plan->tile == 2 || plan->tile == 6)) big = false;   // the plan may ask for 64x64 tiles on wide layers too
-  else if (plan && plan->tile == 5) big = true;
+  else if (plan && plan->tile == 5) {
+    // (mirrors the tuner, mimic_amd/ops.py: _wgrad_candidates -- the 128 tile is never offered with <= 64 channels on a side)
+    if (!big) { set_error("wgrad plan: tile 5 (128x128 on LDS-DMA) needs more than 64 channels on both sides (%d, %d)", g->Cin, g->Cout); return MOPOE_ERR_ARG; }
+  }
   else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6)", plan->tile); return MOPOE_ERR_ARG; }
   const bool glds = plan && plan->tile >= 5;
   if (glds && !vec) { set_error("wgrad plan: the LDS-DMA tiles need the vector path (channel counts %% 4 == 0, aligned tensors)"); return MOPOE_ERR_ARG; }

@@ -632,6 +632,8 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
   if (glds_ok && glds_default) cfg = cfg == 0 ? 5 : (cfg == 3 ? 7 : (cfg == 4 ? 9 : cfg));
   if (plan && plan->tile >= 0) {
     if (plan->tile >= BF16_NTILES) { set_error("bf16 conv plan: tile %d (0..%d)", plan->tile, BF16_NTILES - 1); return MOPOE_ERR_ARG; }
+    // (tile 8 = 256x128 with three buffers spills registers: never offered by the tuner, no longer reachable through a plan)
+    if (plan->tile == 8) { set_error("bf16 conv plan: tile 8 (256x128, three LDS buffers) is not built: it spills registers; use 7"); return MOPOE_ERR_ARG; }
     if (plan->tile >= 5 && (!glds_ok || (a.bn_in.mode != 0 && (plan->tile == 6 || plan->tile == 8 || plan->tile == 10)))) {
       set_error("bf16 conv plan: tile %d (LDS-DMA family) needs K channels %% 64 == 0 (Ck = %d) and, with BN on load, one of the tiles 5, 7, 9, 11", plan->tile, Ck);
       return MOPOE_ERR_ARG;
@@ -697,7 +699,6 @@ static int launch_gather_bf16(const bf16_t* X, const bf16_t* W, const float* bia
       else if (cfg == 5) MOPOE_LAUNCH_G(128, 128, 2, 2, 2);
       else if (cfg == 6) MOPOE_LAUNCH_G(128, 128, 2, 2, 3);
       else if (cfg == 7) MOPOE_LAUNCH_G(256, 128, 4, 2, 2);
-      else if (cfg == 8) MOPOE_LAUNCH_G(256, 128, 4, 2, 3);
       else if (cfg == 9) MOPOE_LAUNCH_G(128, 64, 4, 1, 2);
       else if (cfg == 10) MOPOE_LAUNCH_G(128, 64, 4, 1, 3);
       else MOPOE_LAUNCH_G(64, 64, 2, 2, 4);
@@ -787,7 +788,11 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   const int taps = g->kh * g->kw;
   bool big = g->Cin > 64 && g->Cout > 64;
   if (plan && (plan->tile == 2 || plan->tile == 6)) big = false;
-  if (plan && plan->tile == 5) big = true;
+  if (plan && plan->tile == 5) {
+    // the 128 x 128 LDS-DMA tile on a layer with <= 64 channels on one side would run half-empty MFMA tiles: refused, as the
+    // tuner never offers it (mimic_amd/ops.py: _wgrad_candidates)
+    if (!big) { set_error("bf16 wgrad plan: tile 5 (128x128 on LDS-DMA) needs more than 64 channels on both sides (%d, %d)", g->Cin, g->Cout); return MOPOE_ERR_ARG; }
+  }
   // plan tiles: 0 = 128x128, 2 = 64x64 (register-staged, 32 pixels per chunk); 5 = 128x128, 6 = 64x64 on LDS-DMA (64 pixels
   // per stage).  Default: the LDS-DMA form (MOPOE_BF16_NO_GLDS = the register-staged one).
   static const bool glds_default = !getenv("MOPOE_BF16_NO_GLDS");
@@ -796,7 +801,40 @@ extern "C" int mopoe_conv_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
   // (conv_gemm_bf16_glds.inc, MERGE): convs with Cin = 64 (1), transposed convs with Cout = 64 (2); plain operands, even tap count
   const bool xf_ = a.bn_in.mode != 0;
   const int merge_ok = (!xf_ && taps % 2 == 0) ? (a.x_is_big ? (g->Cin == 64 ? 1 : 0) : (g->Cout == 64 ? 2 : 0)) : 0;
-  if (plan && plan->tile > 7) { set_error("bf16 wgrad plan: tile %d (0, 2, 5, 6, 7)", plan->tile); return MOPOE_ERR_ARG; }
+  if (plan && plan->tile > 9) { set_error("bf16 wgrad plan: tile %d (0, 2, 5, 6, 7, 8, 9)", plan->tile); return MOPOE_ERR_ARG; }
+  // tiles 8 / 9: four taps (one parity class of a k4 s2 p1 kernel) per block, 64 gathered channels x 64 / 128 channels of the
+  // small-grid operand (conv_gemm_bf16_glds.inc: wgrad_parity_bf16_kernel)
+  if (plan && plan->tile >= 8) {
+    const bool ok = !xf_ && g->kh == 4 && g->kw == 4 && g->sh == 2 && g->sw == 2 && g->ph == 1 && g->pw == 1 &&
+                    g->Hs % 8 == 0 && g->Ws % 8 == 0 && g->Hb == 2 * g->Hs && g->Wb == 2 * g->Ws;
+    if (!ok) {
+      set_error("bf16 wgrad plan: tiles 8 / 9 (four taps per block) need a plain operand, k4 s2 p1 and a small grid of whole 8 x 8 tiles");
+      return MOPOE_ERR_ARG;
+    }
+    const int Cg = a.x_is_big ? g->Cin : g->Cout, Csm = a.x_is_big ? g->Cout : g->Cin;
+    const int cs = plan->tile == 9 ? 128 : 64;
+    if (cs == 128 && Csm % 128 != 0) { set_error("bf16 wgrad plan: tile 9 needs a multiple of 128 channels on the small-grid operand"); return MOPOE_ERR_ARG; }
+    const long ntiles = (long)g->N * (g->Hs / 8) * (g->Ws / 8);
+    const long cblocks = (long)ceil_div(Cg, 64) * ceil_div(Csm, cs) * 4;
+    long split = plan->split > 0 ? plan->split : (512 + cblocks - 1) / cblocks;
+    if (split > ntiles) split = ntiles;
+    if (split < 1) split = 1;
+    a.chunk = (ntiles + split - 1) / split;             // (in 8 x 8 tiles)
+    split = (ntiles + a.chunk - 1) / a.chunk;
+    a.atomic = split > 1;
+    static const bool xcd_remap8 = !getenv("MOPOE_NO_XCD_REMAP");
+    a.xcd_remap = xcd_remap8 ? 1 : 0;
+    if (a.atomic && !dwp_is_zero) {
+      if (hipMemsetAsync(dwp, 0, (size_t)taps * g->Cin * g->Cout * sizeof(float), stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
+    }
+    ProfScope prof(stream, 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps, PROF_BF16_WGRAD_PARITY + (cs == 128 ? 1 : 0), (double)xb + (double)db);
+    const dim3 grid((unsigned)(ceil_div(Cg, 64) * ceil_div(Csm, cs)), 4, (unsigned)split);
+    if (cs == 128 && a.x_is_big) hipLaunchKernelGGL((wgrad_parity_bf16_kernel<128, true>), grid, dim3(256), 0, stream, a);
+    else if (cs == 128) hipLaunchKernelGGL((wgrad_parity_bf16_kernel<128, false>), grid, dim3(256), 0, stream, a);
+    else if (a.x_is_big) hipLaunchKernelGGL((wgrad_parity_bf16_kernel<64, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_parity_bf16_kernel<64, false>), grid, dim3(256), 0, stream, a);
+    return check_launch("wgrad_parity_bf16 (four taps per block)");
+  }
   if (plan && plan->tile == 7 && !merge_ok) {
     set_error("bf16 wgrad plan: tile 7 (two taps per block) needs a plain operand, an even tap count and 64 channels on the gathered side");
     return MOPOE_ERR_ARG;

@@ -178,6 +178,112 @@ __global__ __launch_bounds__(256) void token_softmax_grad_kernel(const float* lo
   }
 }
 
+// ---- vocabulary head without a materialised log-softmax (round 4) ---------------------------------------------------------
+// The head GEMM writes the LOGITS once, in the family's storage type (bf16 / fp32).  Training needs two numbers per row of
+// them -- logsumexp and the target's logit -- and, in the backward, softmax - onehot: the [rows, V] fp32 log-probability
+// tensor (461 MB at config #3, written and re-read three times) is never made.  Rows are walked in 16-byte vectors
+// (V % EV == 0, EV = 16 / sizeof(T)); one 256-thread block per row, any V: each thread keeps an online (max, sum).
+template <typename T> struct RowVec;
+template <> struct RowVec<float> {
+  static constexpr int EV = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct RowVec<bf16_t> {
+  static constexpr int EV = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// lse[row] = log sum_v exp(x[row, v])   (columns padded with a very negative bias contribute exp(..) = 0)
+template <typename T>
+__global__ __launch_bounds__(256) void lse_rows_kernel(const T* x, float* lse, int V) {
+  constexpr int EV = RowVec<T>::EV;
+  __shared__ float red_m[4], red_s[4];
+  const long row = blockIdx.x;
+  const T* xr = x + row * V;
+  float m = -INFINITY, s = 0.f;
+  for (int c = threadIdx.x * EV; c < V; c += 256 * EV) {
+    float v[EV];
+    RowVec<T>::load(xr + c, v);
+    float vm = v[0];
+#pragma unroll
+    for (int e = 1; e < EV; ++e) vm = fmaxf(vm, v[e]);
+    const float mn = fmaxf(m, vm);
+    float add = 0.f;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) add += __expf(v[e] - mn);
+    s = s * __expf(m - mn) + add;      // (m = -inf on the first vector: exp(-inf) = 0, s = 0)
+    m = mn;
+  }
+  // combine the threads' (m, s): wave, then block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, mo);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mn));
+    m = mn;
+  }
+  if ((threadIdx.x & 63) == 0) { red_m[threadIdx.x >> 6] = m; red_s[threadIdx.x >> 6] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ss += red_m[w] == -INFINITY ? 0.f : red_s[w] * expf(red_m[w] - mm);
+    lse[row] = mm + logf(ss);
+  }
+}
+
+// out = sum_r (lse[r] - x[r, id_r]) / norm   (= -sum_r log p(id_r) / norm)
+template <typename T>
+__global__ __launch_bounds__(256) void token_nll_logits_fwd_kernel(const T* x, const float* lse, const float* ids, long rows, int V,
+                                                                 float inv_norm, float* out, double* ws, int nblocks) {
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+    int t = (int)ids[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    acc += lse[r] - from_store(x[r * V + t]);
+  }
+  finish_scalar(block_sum_256(acc), ws, nblocks, inv_norm, out);
+}
+
+// dx[r, v] = g / norm * (exp(x[r, v] - lse[r]) - [v == id_r]);  dx may alias x (each vector is read, then written, by one thread)
+template <typename T>
+__global__ __launch_bounds__(256) void token_softmax_grad_logits_kernel(const T* x, const float* lse, const float* ids, const float* g,
+                                                                      int V, float inv_norm, T* dx) {
+  constexpr int EV = RowVec<T>::EV;
+  const long row = blockIdx.x;
+  const float c = g[0] * inv_norm, l = lse[row];
+  int t = (int)ids[row];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  const T* xr = x + row * V;
+  T* dr = dx + row * V;
+  for (int col = threadIdx.x * EV; col < V; col += 256 * EV) {
+    float v[EV];
+    RowVec<T>::load(xr + col, v);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) v[e] = c * (__expf(v[e] - l) - (col + e == t ? 1.f : 0.f));
+    RowVec<T>::store(dr + col, v);
+  }
+}
+
 // ---- token NLL -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void token_nll_fwd_kernel(const float* logp, const float* ids, long rows, int V,
                                                           float inv_norm, float* out, double* ws, int nblocks) {
@@ -371,6 +477,43 @@ extern "C" int mopoe_token_softmax_grad(const float* logp, const float* ids, con
   else MOPOE_TSG(32);
 #undef MOPOE_TSG
   return check_launch("token_softmax_grad");
+}
+
+extern "C" int mopoe_lse_rows(const void* logits, int32_t is_bf16, int64_t rows, int32_t V, float* lse, void* stream) {
+  const int ev = is_bf16 ? 8 : 4;
+  if (!logits || !lse || rows <= 0 || rows > 0x7fffffffL || V <= 0 || V % ev != 0 || ((uintptr_t)logits & 15)) {
+    set_error("lse_rows: bad arguments (V must be a multiple of %d, rows 16-byte aligned)", ev); return MOPOE_ERR_ARG;
+  }
+  const dim3 grid((unsigned)rows), blk(256);
+  if (is_bf16) hipLaunchKernelGGL(lse_rows_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)logits, lse, V);
+  else hipLaunchKernelGGL(lse_rows_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)logits, lse, V);
+  return check_launch("lse_rows");
+}
+
+extern "C" int mopoe_token_nll_logits_fwd(const void* logits, int32_t is_bf16, const float* lse, const float* ids, int64_t rows,
+                                          int32_t V, float norm, float* out, double* ws, void* stream) {
+  if (!logits || !lse || !ids || !out || !ws || rows <= 0 || V <= 0 || norm <= 0.f) { set_error("token_nll_logits_fwd: bad arguments"); return MOPOE_ERR_ARG; }
+  const int nb = stream_grid(rows, 1);
+  if (is_bf16) hipLaunchKernelGGL(token_nll_logits_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
+                                  lse, ids, (long)rows, V, 1.0f / norm, out, ws, nb);
+  else hipLaunchKernelGGL(token_nll_logits_fwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)logits, lse, ids,
+                          (long)rows, V, 1.0f / norm, out, ws, nb);
+  return check_launch("token_nll_logits_fwd");
+}
+
+extern "C" int mopoe_token_softmax_grad_logits(const void* logits, int32_t is_bf16, const float* lse, const float* ids, const float* g,
+                                               int64_t rows, int32_t V, float norm, void* dx, void* stream) {
+  const int ev = is_bf16 ? 8 : 4;
+  if (!logits || !lse || !ids || !g || !dx || rows <= 0 || rows > 0x7fffffffL || V <= 0 || V % ev != 0 || norm <= 0.f ||
+      ((uintptr_t)logits & 15) || ((uintptr_t)dx & 15)) {
+    set_error("token_softmax_grad_logits: bad arguments (V must be a multiple of %d, rows 16-byte aligned)", ev); return MOPOE_ERR_ARG;
+  }
+  const dim3 grid((unsigned)rows), blk(256);
+  if (is_bf16) hipLaunchKernelGGL(token_softmax_grad_logits_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)logits, lse,
+                                  ids, g, V, 1.0f / norm, (bf16_t*)dx);
+  else hipLaunchKernelGGL(token_softmax_grad_logits_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)logits, lse, ids, g, V,
+                          1.0f / norm, (float*)dx);
+  return check_launch("token_softmax_grad_logits");
 }
 
 extern "C" int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm, float* out,

@@ -184,6 +184,10 @@ class VAEtrimodalMimic(BaseMMVae, nn.Module):
         self.lhood_pa = modalities["PA"].likelihood
         self.lhood_lat = modalities["Lateral"].likelihood
         self.lhood_text = modalities["text"].likelihood
+        # the word decoder's head stays factored (logits + row log-sum-exp) on this model's own forward: the [B, L, V] fp32
+        # log-softmax tensor is made only on demand (nets.DecoderText.lazy_head, plugins.LogitsWithLse; MOPOE_LAZY_HEAD=0:
+        # the dense form of rounds 1-3)
+        self.decoder_text.lazy_head = os.environ.get("MOPOE_LAZY_HEAD", "1") != "0"
         # prefixes let a replayed dropout-mask dict use whole-model names (tests)
         for name in ("encoder_pa", "encoder_lat", "encoder_text", "decoder_pa", "decoder_lat", "decoder_text"):
             getattr(self, name)._net_name = name

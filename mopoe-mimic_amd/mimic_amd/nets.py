@@ -689,17 +689,32 @@ class DecoderText(_HipNet):
             return self.text_generator.conv2
         return self.text_generator.generator[len(self.text_generator.plan)]
 
-    _out_names = ("logp_pad",)
+    # The word head on the model's own path (mmvae.forward -> run_group) is LAZY: the decoder node returns the head's logits in
+    # the storage type + their row log-sum-exp, and the likelihood works from those (plugins.LogitsWithLse): the [B, L, V] fp32
+    # log-softmax tensor of the reference (DataGeneratorText.py:76-77) is only made when somebody asks for it.  The public
+    # forward(z_style, z_content) keeps the reference's contract and returns the dense log-probabilities.
+    lazy_head = False
+    _lazy_call = False
+
+    @property
+    def _out_names(self):
+        return ("logits_pad", "lse") if self._lazy_call else ("logp_pad",)
 
     def _group_inputs(self, z_style, z_content):
+        object.__setattr__(self, "_lazy_call", bool(self.lazy_head and not self.char))
         return (z_content,)
 
     def forward(self, z_style, z_content):
-        return self._finish(self._call(*self._group_inputs(z_style, z_content)))
+        object.__setattr__(self, "_lazy_call", False)
+        return self._finish(self._call(z_content))
 
     def _finish(self, outs):
-        (logp_pad,) = outs
         hc = getattr(self, "_head_ctx_latest", None)
+        if len(outs) == 2:
+            from .plugins import LogitsWithLse
+            logits_pad, lse = outs
+            return [LogitsWithLse(logits_pad, lse, self.vocab, hc if logits_pad.requires_grad else None)]
+        (logp_pad,) = outs
         if hc is not None and logp_pad.requires_grad:
             logp_pad._mopoe_head_ctx = hc
         if self.vpad == self.vocab:
@@ -724,8 +739,14 @@ class DecoderText(_HipNet):
             logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Wb, gh.Cout)
         else:
             w_pad, b_pad = self._padded_head()
-            logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
-            logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
+            if self._lazy_call:
+                # logits written ONCE, in the storage type (bf16 family: a stored tensor, rounded where it is written); the
+                # row log-sum-exp is the only other thing the token likelihood and its gradient need
+                logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad).view(b, gh.Ws, gh.Cout)
+                lse = ops.lse_rows(logits)
+            else:
+                logits = ops.conv_fwd(ht, w_pad, gh, bias=b_pad, out_dtype=torch.float32)
+                logp = ops.logsoftmax_fwd(logits, inplace=True).view(b, gh.Ws, gh.Cout)
         hc = None
         if not self.char:         # (grad mode is off inside an autograd Function's forward: forward() decides whether to expose it)
             from .plugins import HeadCtx
@@ -733,14 +754,51 @@ class DecoderText(_HipNet):
         object.__setattr__(self, "_head_ctx_latest", hc)
         if self.training:
             apply_running_updates(running)
+        if self._lazy_call and not self.char:
+            return (logits, lse), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logits=logits, lse=lse, lazy=True, arena=arena,
+                                       head_ctx=hc)
         return (logp,), dict(z4=z4, ht=ht, trunk=saved, gl=gl, gh=gh, logp=logp, arena=arena, head_ctx=hc)
 
-    def _run_backward(self, sv, in_needs_grad, glogp):
+    def _lazy_head_grad(self, sv, glogits_in, glse_in):
+        """gradient of the head's logits on the lazy path: the token likelihood's (handed over through HeadCtx, one pass) plus
+        whatever arrived for (logits, lse) from other consumers (dense(): logp = logits - lse, so d/dlogits gets
+        g_logits + g_lse * softmax)"""
+        from .plugins import is_zero_placeholder
+        hc = sv.get("head_ctx")
+        pend = hc.pending if hc is not None else None
+        if hc is not None:
+            hc.pending = None
+        logits, lse = sv["logits"], sv["lse"]
+        total = None
+        if pend is not None:
+            ids, g, norm = pend
+            total = ops.token_softmax_grad_logits(logits, lse, ids, g, norm)
+        dense = None
+        if glogits_in is not None and not is_zero_placeholder(glogits_in):
+            dense = glogits_in.float()
+        if glse_in is not None and not is_zero_placeholder(glse_in):
+            via_lse = glse_in.float().unsqueeze(-1) * torch.exp(logits.float() - lse.unsqueeze(-1))
+            dense = via_lse if dense is None else dense + via_lse
+        if dense is not None:
+            total = dense.to(self.act_dtype) if total is None else (total.float() + dense).to(self.act_dtype)
+        if total is None:
+            total = torch.zeros_like(logits)
+        return total.contiguous()
+
+    def _run_backward(self, sv, in_needs_grad, glogp, glse=None):
         grads: Dict[str, torch.Tensor] = {}
-        b = glogp.shape[0]
+        dev = next(t.device for t in (glogp, glse) if t is not None)
         gh, gl = sv["gh"], sv["gl"]
-        ar = BackwardArena(self.blocks, glogp.device, extra=self._misc_numel())
-        if self.char:
+        b = gh.N
+        ar = BackwardArena(self.blocks, dev, extra=self._misc_numel())
+        if sv.get("lazy"):
+            glogits = self._lazy_head_grad(sv, glogp, glse).view(b, 1, gh.Ws, gh.Cout)
+            k = len(self.blocks)
+            w_pad = self._head_pad[0]
+            grads[f"text_generator.generator.{k}.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh)[:, :, :self.vocab].contiguous()
+            grads[f"text_generator.generator.{k}.bias"] = ops.colsum(glogits)[:self.vocab]
+            dht = ops.conv_dgrad(glogits, w_pad, gh)
+        elif self.char:
             glogits = ops.logsoftmax_bwd(glogp, sv["logp"]).view(b, 1, gh.Wb, gh.Cout)
             grads["text_generator.conv2.weight"] = ops.conv_wgrad(sv["ht"], glogits, gh, out=ar.take_misc((gh.taps, gh.Cin, gh.Cout)))
             grads["text_generator.conv2.bias"] = ops.colsum(glogits, out=ar.take_misc((glogits.shape[-1],)))

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -389,6 +389,21 @@ def _wgrad_candidates(g: Geom, bf16: bool = False, plain_operand: bool = False):
             if s not in seen:
                 seen.add(s)
                 cands[(7, s)] = min(1.0, tiles * s / 768)
+    # tile 8 (bf16, plain operand, k4 s2 p1, small grid of whole 8 x 8 tiles): four taps -- one parity class -- per block
+    if (bf16 and BF16_GLDS and WGRAD_PARITY and plain_operand and (g.kh, g.kw, g.sh, g.sw, g.ph, g.pw) == (4, 4, 2, 2, 1, 1)
+            and g.Hs % 8 == 0 and g.Ws % 8 == 0 and g.Hb == 2 * g.Hs and g.Wb == 2 * g.Ws):
+        cg, csm = (g.Cout, g.Cin) if g.transposed else (g.Cin, g.Cout)
+        ntiles = g.N * (g.Hs // 8) * (g.Ws // 8)
+        for tile, cs in ((8, 64), (9, 128)):       # 64 gathered channels x 64 / 128 channels of the small-grid operand
+            if csm % cs:
+                continue
+            tiles = -(-cg // 64) * (csm // cs) * 4
+            seen = set()
+            for target in (256, 512, 768, 1024, 2048):
+                s = max(1, min(-(-target // tiles), ntiles))
+                if s not in seen:
+                    seen.add(s)
+                    cands[(tile, s)] = min(1.0, tiles * s / (256 if cs == 128 else 512))
     # tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_glds.inc, conv_gemm_bf16_glds.inc)
     glds = (BF16_GLDS if bf16 else F32_GLDS and g.Cin % 4 == 0 and g.Cout % 4 == 0)
     for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))):
@@ -475,6 +490,7 @@ _GATHER_TILES_BF16 = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64),
                       (128, 128), (128, 128), (256, 128), (256, 128), (128, 64), (128, 64), (64, 64))
 _GLDS_TILES = {5: 512, 6: 256, 7: 256, 9: 768, 10: 512, 11: 512}     # tile -> blocks resident at once (8 spills: not offered)
 BF16_GLDS = os.environ.get("MOPOE_BF16_GLDS", "1") != "0"      # A/B switch: keep the tuner on the register-staged tiles
+WGRAD_PARITY = os.environ.get("MOPOE_WGRAD_PARITY", "1") != "0"  # A/B switch: wgrad tile 8 (four taps per block) offered
 
 
 def _is16(t):
@@ -898,6 +914,35 @@ def token_softmax_grad(logp, ids, g, norm, out_dtype=None):
     return dx
 
 
+def lse_rows(logits):
+    """logits [..., V] (fp32 or bf16, contiguous, V a multiple of 4 / 8) -> log-sum-exp per row, fp32 [...]"""
+    _dev(logits)
+    assert logits.is_contiguous()
+    lse = torch.empty(logits.shape[:-1], dtype=torch.float32, device=logits.device)
+    _check(lib().mopoe_lse_rows(_p(logits), C.c_int32(int(logits.dtype == BF16)), C.c_int64(_rows(logits)), logits.shape[-1],
+                                _p(lse), _stream()))
+    return lse
+
+
+def token_nll_logits_fwd(logits, lse, ids, norm):
+    """sum_r (lse[r] - logits[r, ids[r]]) / norm: the token NLL from the head's logits and their row log-sum-exp"""
+    _dev(logits, lse, ids)
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    _check(lib().mopoe_token_nll_logits_fwd(_p(logits), C.c_int32(int(logits.dtype == BF16)), _p(lse), _p(ids),
+                                            C.c_int64(ids.numel()), logits.shape[-1], C.c_float(norm), _p(out),
+                                            _p(_ws(logits.device)), _stream()))
+    return out
+
+
+def token_softmax_grad_logits(logits, lse, ids, g, norm, inplace=False):
+    """gradient of the logits for the token NLL from the logits themselves: g / norm * (softmax - onehot), in logits' dtype"""
+    _dev(logits, lse, ids, g)
+    dx = logits if inplace else torch.empty_like(logits)
+    _check(lib().mopoe_token_softmax_grad_logits(_p(logits), C.c_int32(int(logits.dtype == BF16)), _p(lse), _p(ids), _p(g),
+                                                 C.c_int64(ids.numel()), logits.shape[-1], C.c_float(norm), _p(dx), _stream()))
+    return dx
+
+
 def token_nll_fwd(logp, ids, norm):
     _dev(logp, ids)
     out = torch.empty(1, dtype=torch.float32, device=logp.device)
@@ -995,7 +1040,8 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 122
+    names = [None] * 124
+    names[122], names[123] = "wgrad_parity_bf16_kernel<64, *>", "wgrad_parity_bf16_kernel<128, *>"
     for m in (1, 2):
         names[120 + m - 1] = f"wgrad_gemm_bf16_glds_kernel<128, false, true, {m}>"
     for i, (tt, st) in enumerate((("128", (2, 2)), ("64", (4, 2)))):

@@ -48,17 +48,19 @@ class HeadCtx:
 _zero_scalars = {}
 
 
-def zero_placeholder(shape, device):
-    """a zero tensor of `shape` that occupies 4 bytes (stride 0); is_zero_placeholder() recognises it"""
-    key = (device.type, device.index)
+def zero_placeholder(shape, device, dtype=torch.float32):
+    """a zero tensor of `shape` that occupies one element (stride 0); is_zero_placeholder() recognises it.  `dtype` must be the
+    dtype of the tensor whose gradient it stands for: autograd casts a gradient of another dtype -- which would materialise
+    the whole [B, L, V] tensor this placeholder exists to avoid"""
+    key = (device.type, device.index, dtype)
     z = _zero_scalars.get(key)
     if z is None:
-        z = _zero_scalars[key] = torch.zeros(1, dtype=torch.float32, device=device)
+        z = _zero_scalars[key] = torch.zeros(1, dtype=dtype, device=device)
     return z.expand(shape)
 
 
 def is_zero_placeholder(t) -> bool:
-    z = _zero_scalars.get((t.device.type, t.device.index))
+    z = _zero_scalars.get((t.device.type, t.device.index, t.dtype))
     return z is not None and t.data_ptr() == z.data_ptr() and all(s == 0 for s in t.stride())
 
 
@@ -78,6 +80,62 @@ class _TokenNll(torch.autograd.Function):
             ctx.head.pending = (ids, g.contiguous(), ctx.norm)
             return zero_placeholder(ctx.shape, g.device), None, None
         return ops.token_nll_bwd(ids, g.contiguous(), ctx.shape, ctx.norm), None, None
+
+
+class LogitsWithLse:
+    """What the word text decoder hands to the likelihood on the model's own path (nets.DecoderText, lazy head): the head's
+    LOGITS [B, L, Vpad] in the family's storage type plus their row log-sum-exp [B, L] (fp32) -- the reference's
+    LogSoftmax output (word_encoding/DataGeneratorText.py:76-77) in factored form.  The token likelihood and its gradient
+    need only these (ops.token_nll_logits_fwd / token_softmax_grad_logits); the dense [B, L, V] fp32 log-probabilities are
+    made on demand (`dense()`: evaluation, generation, the likelihood estimator, tests)."""
+
+    def __init__(self, logits_pad, lse, vocab, head_ctx=None):
+        self.logits_pad, self.lse, self.vocab, self.head_ctx = logits_pad, lse, vocab, head_ctx
+        self._dense = None
+
+    @property
+    def shape(self):
+        return torch.Size((*self.logits_pad.shape[:-1], self.vocab))
+
+    def dim(self):
+        return self.logits_pad.dim()
+
+    def dense_padded(self):
+        """fp32 log-probabilities over the padded vocabulary (pad columns ~ -1e30), connected to autograd"""
+        if self._dense is None:
+            self._dense = self.logits_pad.float() - self.lse.unsqueeze(-1)
+        return self._dense
+
+    def dense(self):
+        lp = self.dense_padded()
+        if lp.shape[-1] == self.vocab:
+            return lp
+        out = lp[..., :self.vocab]
+        out._mopoe_padded = lp
+        return out
+
+
+class _TokenNllLogits(torch.autograd.Function):
+    """token NLL from (logits, row log-sum-exp): sum_r (lse_r - logits[r, id_r]) / norm"""
+
+    @staticmethod
+    def forward(ctx, logits, lse, ids, norm, head):
+        ids_c = ids.contiguous()
+        ctx.save_for_backward(ids_c)
+        ctx.shape, ctx.norm, ctx.head, ctx.dtype = tuple(logits.shape), norm, head, logits.dtype
+        return ops.token_nll_logits_fwd(logits, lse, ids_c, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        if ctx.head is not None and ctx.head.pending is None:
+            # the decoder's backward makes the logits' gradient in one pass from what is handed over here
+            ctx.head.pending = (ids, g.contiguous(), ctx.norm)
+            return (zero_placeholder(ctx.shape, g.device, ctx.dtype), zero_placeholder(ctx.shape[:-1], g.device), None, None, None)
+        # general form (a second likelihood on the same decoder output): d/dlogits = -onehot g / norm, d/dlse = g / norm
+        c = g.reshape(()) / ctx.norm
+        return (ops.token_nll_bwd(ids, g.contiguous(), ctx.shape, ctx.norm).to(ctx.dtype), c.expand(ctx.shape[:-1]).contiguous(),
+                None, None, None)
 
 
 class _DenseNll(torch.autograd.Function):
@@ -128,12 +186,23 @@ class FusedLaplace:
 
 
 class FusedOneHotCategorical:
-    """Stand-in for torch.distributions.OneHotCategorical(logits=log-probabilities [B,L,V])."""
+    """Stand-in for torch.distributions.OneHotCategorical(logits=log-probabilities [B,L,V]).  `logits` is either that dense
+    tensor or a LogitsWithLse (the word decoder's factored output): `.logits` then materialises the dense tensor on demand."""
 
     def __init__(self, probs=None, logits=None):
         if logits is None:
             raise NotImplementedError("construct with logits= (the text decoder emits log-probabilities)")
-        self.logits = logits
+        self._lazy = logits if isinstance(logits, LogitsWithLse) else None
+        self._logits = None if self._lazy is not None else logits
+
+    @property
+    def logits(self):
+        return self._lazy.dense() if self._lazy is not None else self._logits
+
+    @property
+    def logits_dim(self):
+        """number of dimensions of the log-probability tensor, without materialising it"""
+        return self._lazy.dim() if self._lazy is not None else self._logits.dim()
 
     @property
     def probs(self):
@@ -150,8 +219,11 @@ class FusedOneHotCategorical:
         """target_ids: float-encoded token ids [B,L] (no one-hot is ever materialised).  The text decoder hands over a
         [..., :V] view of a contiguous tensor padded along V (pad log-probabilities = -1e30): the reductions index the
         padded tensor directly, so neither a compaction copy nor a slice-gradient pass exists."""
-        if target_ids.dim() == self.logits.dim():   # char encoding: the [B, L, num_features] one-hot tensor itself
+        if target_ids.dim() == self.logits_dim:   # char encoding: the [B, L, num_features] one-hot tensor itself
             return _DenseNll.apply(self.logits, target_ids, float(norm_value)).view(())
+        if self._lazy is not None:                # word encoding, factored head: no log-softmax tensor at all
+            z = self._lazy
+            return _TokenNllLogits.apply(z.logits_pad, z.lse, target_ids, float(norm_value), z.head_ctx).view(())
         lp = getattr(self.logits, "_mopoe_padded", self.logits)
         return _TokenNll.apply(lp, target_ids, float(norm_value)).view(())
 
@@ -161,9 +233,9 @@ class FusedOneHotCategorical:
     def log_prob_rows(self, target_ids):
         """per-row sum over the sequence of the picked log-probabilities: logits [R,L,V] against float ids [B,L]
         repeated R/B times (row r <-> r % B); evaluation only."""
-        if target_ids.dim() == self.logits.dim():   # char encoding: dense [B, L, num_features] target
+        if target_ids.dim() == self.logits_dim:   # char encoding: dense [B, L, num_features] target
             return ops.dense_logprob_rows(self.logits.detach().contiguous(), target_ids.contiguous())
-        lp = getattr(self.logits, "_mopoe_padded", self.logits)
+        lp = self._lazy.dense_padded() if self._lazy is not None else getattr(self.logits, "_mopoe_padded", self.logits)
         return ops.token_logprob_rows(lp.detach().contiguous(), target_ids.contiguous())
 
 
@@ -266,12 +338,12 @@ class MimicText(Modality):
             if hasattr(out_dist, "summed_log_prob"):
                 return out_dist.summed_log_prob(target, norm_value)
             return out_dist.log_prob(target).sum() / norm_value
-        if hasattr(out_dist, "summed_log_prob") and target.dim() == out_dist.logits.dim() - 1:
+        if hasattr(out_dist, "summed_log_prob") and target.dim() == out_dist.logits_dim - 1:
             return out_dist.summed_log_prob(target, norm_value)  # float ids, as the data loader yields them
         onehot = torch.nn.functional.one_hot(target.to(torch.int64), num_classes=self.args.vocab_size)
         return out_dist.log_prob(onehot).sum() / norm_value
 
     def calc_nll(self, out_dist, target: torch.Tensor, norm_value: int):
         fused = hasattr(out_dist, "summed_nll") and (self.args.text_encoding == "char"
-                                                     or target.dim() == out_dist.logits.dim() - 1)
+                                                     or target.dim() == out_dist.logits_dim - 1)
         return out_dist.summed_nll(target, norm_value) if fused else -self.calc_log_prob(out_dist, target, norm_value)

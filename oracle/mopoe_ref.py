@@ -390,10 +390,10 @@ def decode_text(cfg: Cfg, sd, z, ctx: Ctx):
         h = _resblock(sd, f"{p}.{i}.0", h, ctx, stride=s, pad=pd, transposed=True, twod=False,
                       short_name="upsample")
     k = len(blocks)
-    # ctx.bf16: bf16 operands, fp32 logits and log-probabilities; their gradient re-enters the GEMMs in bf16
-    logits = F.conv1d(h, _qw(sd[f"{p}.{k}.weight"], ctx), sd[f"{p}.{k}.bias"])
-    if ctx.bf16:
-        logits = _GradRoundBf16.apply(logits)
+    # ctx.bf16: bf16 operands; the logits are a STORED tensor of the bf16 family since round 4 (the head GEMM writes them
+    # once, in bf16; log-sum-exp, the target's logit and softmax - onehot are taken from the stored values in fp32), and their
+    # gradient re-enters the GEMMs in bf16
+    logits = _q(F.conv1d(h, _qw(sd[f"{p}.{k}.weight"], ctx), sd[f"{p}.{k}.bias"]), ctx)
     return F.log_softmax(logits, dim=1).transpose(-2, -1)
 
 

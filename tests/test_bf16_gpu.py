@@ -144,6 +144,10 @@ def test_conv_every_launch_plan_bf16(name, g: Geom):
             with ops.force_plan(tile, split):
                 _conv_case(f"{name}/t{tile}s{split}", g)
     for tile in (0, 2, 5, 6):      # 5 / 6: the 128 / 64 tiles on LDS-DMA (64 pixels per stage)
+        if tile == 5 and min(g.Cin, g.Cout) <= 64:     # the 128 tile on a narrow layer: refused (the tuner never offers it)
+            with ops.force_plan(5, 1), pytest.raises(ops.MopoeHipError):
+                ops.conv_wgrad(torch.zeros(g.in_shape, dtype=BF, device=DEV), torch.zeros(g.out_shape, dtype=BF, device=DEV), g)
+            continue
         for split in (1, 2, 5):
             with ops.force_plan(tile, split):
                 gen = torch.Generator().manual_seed(7)
@@ -186,6 +190,47 @@ def test_wgrad_two_taps_per_block_bf16(name, g: Geom):
         g2 = Geom(2, 4, 4, 8, 8, 128, 128, 4, 4, 2, 2, 1, 1, False)
         with pytest.raises(ops.MopoeHipError):
             ops.conv_wgrad(torch.zeros(g2.in_shape, dtype=BF, device=DEV), torch.zeros(g2.out_shape, dtype=BF, device=DEV), g2)
+
+
+PARITY_GEOMS = [
+    ("enc_64to128_b3", Geom(3, 16, 16, 32, 32, 64, 128, 4, 4, 2, 2, 1, 1, False)),      # conv, S tile 128 (rb1's shape)
+    ("enc_128to192_b5", Geom(5, 8, 8, 16, 16, 128, 192, 4, 4, 2, 2, 1, 1, False)),      # two G tiles, S tile 64 (192 = 3 x 64)
+    ("enc_64to64_b2", Geom(2, 8, 16, 16, 32, 64, 64, 4, 4, 2, 2, 1, 1, False)),         # S tile 64, non-square map
+    ("enc_72to136_b2", Geom(2, 8, 8, 16, 16, 72, 136, 4, 4, 2, 2, 1, 1, False)),        # partial channel tiles on both sides
+    ("enc_64to256_b2", Geom(2, 8, 8, 16, 16, 64, 256, 4, 4, 2, 2, 1, 1, False)),        # two S tiles of 128
+    ("dec_128to64_b5", Geom(5, 8, 8, 16, 16, 128, 64, 4, 4, 2, 2, 1, 1, True)),         # transposed: G = dy (64), S = x (128)
+    ("dec_64to64_b3", Geom(3, 16, 16, 32, 32, 64, 64, 4, 4, 2, 2, 1, 1, True)),         # transposed, S tile 64
+    ("dec_192to128_b2", Geom(2, 8, 8, 16, 16, 192, 128, 4, 4, 2, 2, 1, 1, True)),       # transposed, two G tiles, S tile 64
+]
+
+
+@pytest.mark.parametrize("name,g", PARITY_GEOMS, ids=[n for n, _ in PARITY_GEOMS])
+def test_wgrad_four_taps_per_block_bf16(name, g: Geom):
+    """wgrad tile 8 (round 4): one parity class of a k4 s2 p1 kernel -- four taps -- per block, the 9 x 9 big-grid pixels of an
+    8 x 8 tile of small-grid pixels staged once for all of them: every tap of every class against the emulation, with and
+    without a split of the pixel tiles; refused with BN on load, for other kernel shapes and for maps that are not whole tiles"""
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(g.in_shape, generator=gen).to(BF)
+    dy = torch.randn(g.out_shape, generator=gen).to(BF)
+    ref = TB.conv_wgrad(x, dy, g)
+    csm = g.Cin if g.transposed else g.Cout
+    for tile in (8, 9):
+        if tile == 9 and csm % 128:
+            with ops.force_plan(9, 1), pytest.raises(ops.MopoeHipError):
+                ops.conv_wgrad(x.to(DEV), dy.to(DEV), g)
+            continue
+        for split in (1, 2, 5):
+            with ops.force_plan(tile, split):
+                check(f"{name}/wgrad_t{tile}s{split}", ops.conv_wgrad(x.to(DEV), dy.to(DEV), g), ref, rtol=3e-4, atol_rel=3e-4)
+    with ops.force_plan(8, 1):
+        bn = make_bn(g.Cin, x.numel() // g.Cin, 1, gen, x.float())
+        with pytest.raises(ops.MopoeHipError):
+            ops.conv_wgrad(x.to(DEV), dy.to(DEV), g, bn_in=to_dev(bn))
+        for bad in (Geom(2, 6, 5, 12, 10, 64, 64, 4, 4, 2, 2, 1, 1, False),           # not whole 8 x 8 tiles
+                    Geom(2, 1, 16, 1, 32, 64, 64, 1, 4, 1, 2, 0, 1, True),            # 1-D
+                    Geom(2, 4, 4, 16, 16, 64, 64, 4, 4, 4, 4, 1, 1, False)):          # stride 4
+            with pytest.raises(ops.MopoeHipError):
+                ops.conv_wgrad(torch.zeros(bad.in_shape, dtype=BF, device=DEV), torch.zeros(bad.out_shape, dtype=BF, device=DEV), bad)
 
 
 def _glds_case(name, g: Geom):

@@ -12,7 +12,8 @@ layers = {"rb1 64->128 @32": Geom(B, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, 
           "rb2 128->192 @16": Geom(B, 16, 16, 32, 32, 128, 192, 4, 4, 2, 2, 1, 1, False),
           "rb3 192->256 @8": Geom(B, 8, 8, 16, 16, 192, 256, 4, 4, 2, 2, 1, 1, False),
           "g4 T 64->64 @64": Geom(B, 32, 32, 64, 64, 64, 64, 4, 4, 2, 2, 1, 1, True),
-          "g3 T 128->64 @32": Geom(B, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True)}
+          "g3 T 128->64 @32": Geom(B, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True),
+          "g2 T 192->128 @16": Geom(B, 8, 8, 16, 16, 192, 128, 4, 4, 2, 2, 1, 1, True)}
 tiles = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 9, 10]
 def fl(g, kind):
     if kind.startswith("fwd"):
@@ -47,13 +48,15 @@ for name, g in layers.items():
         print(f"{name:18s} {kind:6s} " + "  ".join(row), flush=True)
     if "wgrad" in os.environ.get("KINDS", "").split(","):     # weight gradient, plain operand: tiles 2 / 6 (64), 0 / 5 (128), 7 (two taps per block)
         row = []
-        for tile in (2, 6, 0, 5, 7):
+        for tile in (2, 6, 0, 5, 7, 8, 9):      # 8 / 9: four taps (a parity class) per block, S tile 64 / 128
             if tile in (0, 5) and min(g.Cin, g.Cout) <= 64:
                 continue
             if tile == 7 and (g.Cout if g.transposed else g.Cin) != 64:
                 continue
+            if tile == 9 and (g.Cin if g.transposed else g.Cout) % 128:
+                continue
             best = None
-            for split in (16, 32, 64, 128):
+            for split in ((4, 8, 16, 32, 64, 128, 256) if tile >= 8 else (16, 32, 64, 128)):
                 with ops.force_plan(tile, split):
                     for _ in range(3): ops.conv_wgrad(x, dy, g)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -21,7 +21,8 @@ OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_relu_ap
             "bn_bwd_apply", "bn_running_update", "colsum", "latent_fwd", "latent_bwd", "laplace_nll_fwd",
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
-            "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad", "adam_step"]
+            "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad", "adam_step", "lse_rows",
+            "token_nll_logits_fwd", "token_softmax_grad_logits"]
 
 
 def install(monkeypatch):
@@ -388,6 +389,23 @@ def token_logprob_rows(logp, ids):
     rows, tb = logp.shape[0], ids.shape[0]
     idx = ids.long().repeat(rows // tb, 1)
     return logp.gather(-1, idx.unsqueeze(-1)).squeeze(-1).sum(dim=1)
+
+
+def lse_rows(logits):
+    return torch.logsumexp(_f(logits), dim=-1)
+
+
+def token_nll_logits_fwd(logits, lse, ids, norm):
+    x = _f(logits).reshape(-1, logits.shape[-1])
+    picked = torch.gather(x, 1, ids.reshape(-1, 1).long().clamp(0, logits.shape[-1] - 1)).reshape(-1)
+    return ((lse.reshape(-1).double() - picked.double()).sum() / norm).float().reshape(1)
+
+
+def token_softmax_grad_logits(logits, lse, ids, g, norm, inplace=False):
+    c = _f(g).reshape(()) / norm
+    x = _f(logits)
+    onehot = torch.zeros_like(x).scatter_(-1, ids.long().clamp(0, x.shape[-1] - 1).unsqueeze(-1), 1.0)
+    return (c * (torch.exp(x - lse.unsqueeze(-1)) - onehot)).to(logits.dtype)
 
 
 def token_softmax_grad(logp, ids, g, norm, out_dtype=None):
