@@ -213,6 +213,7 @@ def main():
     torch.manual_seed(1234 + rank)
 
     host_done = [0.0]
+    t_setup = time.perf_counter()
     trace = int(os.environ.get("MOPOE_BENCH_TRACE", "0"))
     hist = []
     graphed = None
@@ -230,6 +231,9 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, async_op=True).wait()   # (asynchronous: mimic_amd/parallel.py, docstring)
         if use_graph and ok.item() < 0.5:
             graphed, use_graph = None, False
+
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup    # (two eager steps + the capture; with the committed plan table no tuning)
 
     def run(nsteps, start=0, eager=False):
         for i in range(nsteps):
@@ -332,6 +336,7 @@ def main():
             gbs = by / (ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc passes of an earlier run, not measured in this one)") if traffic is not None else None,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                         "bytes_per_launch": by / n, "flops_per_launch": fl / n,
                         "mfma_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
@@ -344,6 +349,7 @@ def main():
             achieved = fl / (ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc passes of an earlier run, not measured in this one)") if traffic is not None else None,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                         "flops_per_launch": fl / n, "bytes_per_launch": by / n,
                         "algorithmic_gbs": round(by / (ms * 1e-3) / 1e9, 1),
@@ -375,6 +381,9 @@ def main():
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),
                        "host_ms_per_step_call_idle_queue": round(host_call_ms, 3),
                        "host_enqueue_ms_per_step": round(host_ms, 3), "hip_graph": bool(use_graph),
+                       # launch plans: the committed table (mimic_amd/plans_gfx950.json) or the in-process tuner
+                       "launch_plans": ops.plan_source_summary(),
+                       "setup_s": round(setup_s, 2),
                        "model_tflops": round(FLOPS_PER_SAMPLE[args.config] * value / 1e12, 2),
                        ("model_frac_of_bf16_mfma_peak" if cdtype == "bf16" else "model_frac_of_fp32_mfma_peak"):
                            round(FLOPS_PER_SAMPLE[args.config] * value / 1e12

@@ -295,6 +295,15 @@ def _table_plan(key):
     return True, (None if v is None else _Plan(int(v[0]), int(v[1])))
 
 
+_plan_sources = {"table": 0, "tuned": 0, "static": 0}
+
+
+def plan_source_summary():
+    """how the launch plans in use were obtained: counts of (op, geometry, fusion) triples from the committed table, from the
+    in-process tuner, and left on the library's static heuristic"""
+    return dict(_plan_sources, table_file=os.path.basename(PLAN_TABLE_PATH) if USE_PLAN_TABLE and os.path.exists(PLAN_TABLE_PATH) else None)
+
+
 def clear_plans():
     _plans.clear()
 
@@ -444,6 +453,7 @@ def _tuned_plan(key, cands_fn, launch):
     found, p = _table_plan(key)
     if found:
         _plans[key] = p
+        _plan_sources["table"] += 1
         return None if p is None else C.byref(p)
     if torch.cuda.is_current_stream_capturing():
         return None
@@ -481,6 +491,7 @@ def _tuned_plan(key, cands_fn, launch):
         best = plans[min(finalists, key=score)]
     _plans[key] = best
     _plan_log[key] = timings
+    _plan_sources["tuned" if len(cands) > 1 else "static"] += 1
     return None if best is None else C.byref(best)
 
 

@@ -39,6 +39,7 @@ from golden_util import pack_grad, pack_bits, weights_fingerprint, rec_sample_in
 
 C2 = dict(img_size=128, class_dim=128, DIM_img=64, DIM_text=128, vocab_size=3517)
 C5 = dict(img_size=256, class_dim=256, DIM_img=64, DIM_text=128, vocab_size=3517)
+SMALL = dict(img_size=64, class_dim=32, DIM_img=32, DIM_text=32, vocab_size=200)
 # name -> (cfg kwargs, rows, seed, mode, family, truth); seeds / modes are the ones the round-3 live-oracle tests used
 CASES = {
     "c2_b8": (C2, 8, 21, "train_nodrop", "fp32", "ref64"),
@@ -48,6 +49,11 @@ CASES = {
     "c5_b4": (C5, 4, 31, "train_nodrop", "fp32", "ref64"),
     "c3_b256_bf16": (C2, 256, 91, "train_nodrop", "bf16", "ref32"),
     "c5_b32_bf16": (C5, 32, 95, "train_nodrop", "bf16", "ref32"),
+    # a small configuration the bf16 family accepts (every GEMM K a multiple of 32): BatchNorm batch statistics, dropout (the
+    # oracle's seeded masks: its fp32 pass is then the oracle's too), eval (running statistics, forward only)
+    "small_bf16_nodrop": (SMALL, 8, 71, "train_nodrop", "bf16", "ref32"),
+    "small_bf16_dropout": (SMALL, 8, 72, "train", "bf16", "oracle32"),
+    "small_bf16_eval": (SMALL, 8, 73, "eval", "bf16", "oracle32"),
 }
 def scalars_to_store(store, prefix, total, klds, log_probs):
     store[f"{prefix}/total_loss"] = np.array(float(total))
@@ -183,6 +189,14 @@ def gen_case(run_epochs, name):
     print(f"[{name}] inputs ready ({time.time() - t0:.0f} s)")
 
     # ---- the fp32 pass of the reference arithmetic (the reference itself unless dropout masks must be replayed)
+    if mode == "eval":          # forward only (running statistics): scalars and reconstructions of both arithmetics
+        with torch.no_grad():
+            o32 = R.forward_step(cfg, sd, batch, eps, mk())
+            o16 = R.forward_step(cfg, sd, batch, eps, mk(bf16=True))
+        for tag, o in (("fp32", o32), ("bf16", o16)):
+            scalars_to_store(store, tag, o["total_loss"], o["klds"], o["log_probs"])
+            rec_to_store(store, tag, o["rec"])
+        return store
     o32, go32 = oracle_pass(cfg, sd, batch, eps, mk)
     if mode == "train":
         out32 = dict(total_loss=o32["total_loss"], klds=o32["klds"], log_probs=o32["log_probs"], rec=o32["rec"])

@@ -121,7 +121,7 @@ def check_fp32_case(case, q90_tol=2e-3, trim_tol=4e-3, l2_tol=5e-2, zero_tol=5e-
     return exp, cfg
 
 
-def check_bf16_case(case):
+def check_bf16_case(case, small_batch=False, grads=True):
     """bf16 HIP path against a G7 case: forward scalars against the bf16-mode oracle (3e-3) and the REFERENCE's fp32 run
     (rtol 2e-2); reconstruction samples; every parameter gradient against the bf16-mode oracle's and the
     reference's fp32 gradient.  Gates (derived from gpurun_out/bf16_parity.log, round 3: C3 at B = 256, tensors above the
@@ -134,7 +134,8 @@ def check_bf16_case(case):
                         over all regular tensors: median <= 4e-2, 90th percentile <= 0.11, median cosine >= 0.998
       analytically zero gradients (both sides hold pure rounding noise): |error| <= half the bf16 noise floor of the tensor
     A gradient that is wrong by 20 % in one tensor fails the first line.  (Norms of differences are count-sketch estimates,
-    8.8 % relative standard deviation: tests/golden_util.py.)"""
+    8.8 % relative standard deviation: tests/golden_util.py.)  small_batch (B <= 16: fewer rows per gradient, measured in round 3:
+    median 3.0e-2, p90 9.1e-2, max 1.5e-1): 0.22 / 0.975 / 6e-2 / 0.15.  grads=False: an eval-mode case, forward only."""
     g = load(f"g7_{case}")
     cfg, sd, batch, eps, masks = g7_inputs(g)
     exp = build_exp(cfg, sd, "cuda", str(g["mode"]), masks=masks, eps=eps, compute_dtype="bf16")
@@ -148,12 +149,14 @@ def check_bf16_case(case):
     for m in ("PA", "Lateral"):
         err = (_rec_samples(got, m) - torch.from_numpy(g[f"bf16/rec/{m}"]).double()).abs()
         assert err.mean().item() <= 2e-3 * float(g[f"bf16/recmax/{m}"]), (case, m, err.mean().item())
+    if not grads:
+        return exp, cfg, g
     exp.mm_vae.zero_grad()
     got["total_loss"].backward()
     grads = exp.mm_vae.reference_named_grads()
     names, numel, meta = [str(n) for n in g["grad_names"]], g["grad_numel"], g["grad_meta"]
     assert set(grads) == set(names)
-    cap, cos_min, med_max, p90_max = 0.15, 0.985, 4e-2, 0.11
+    cap, cos_min, med_max, p90_max = (0.22, 0.975, 6e-2, 0.15) if small_batch else (0.15, 0.985, 4e-2, 0.11)
     bad, cos_all, rel_reg = [], [], []
     for name, n, (scale, e_ref32) in zip(names, numel, meta):
         gr = grads[name]

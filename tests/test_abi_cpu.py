@@ -75,3 +75,26 @@ def test_every_collective_is_asynchronous():
                 bad.append(f"{os.path.relpath(path, REPO)}:{node.lineno} dist.{node.func.attr}")
     assert seen >= 5, seen
     assert not bad, bad
+
+
+def test_committed_plan_table_is_well_formed():
+    """mimic_amd/plans_gfx950.json (tests/tools/make_plan_table.py on an MI355X): every key is op|14 geometry numbers|fusion
+    flags, every value null (static heuristic) or [tile, split] inside the ranges include/mopoe_hip.h documents; a known
+    BASELINE triple is found through ops._table_plan, an unknown one is not (the tuner then runs for it)."""
+    import json
+    from mimic_amd import ops
+    with open(ops.PLAN_TABLE_PATH) as f:
+        table = json.load(f)
+    plans = table["plans"]
+    assert len(plans) >= 500 and set(table["meta"]["configs"]) >= {"c2", "c3", "c5"}
+    for key, v in plans.items():
+        op, geo, _flags = key.split("|")
+        assert op in ("fwd", "dgrad", "wgrad", "fwd16", "dgrad16", "wgrad16"), key
+        assert len(geo.split(",")) == 14 and all(x.lstrip("-").isdigit() for x in geo.split(",")), key
+        assert v is None or (len(v) == 2 and 0 <= v[0] <= 15 and 1 <= v[1] <= 4096), (key, v)
+    # rb1's shortcut conv at config #2 (B = 64): forward, no BN on load, no mask, statistics
+    g = ops.Geom(64, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False)
+    found, _ = ops._table_plan(("fwd", g, False, False, True))
+    assert found
+    found, _ = ops._table_plan(("fwd", ops.Geom(3, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False), False, False, True))
+    assert not found
