@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 15
+#define MOPOE_ABI_VERSION 16
 
 /* error codes */
 #define MOPOE_OK 0
@@ -55,7 +55,9 @@ typedef struct {
 } mopoe_conv_geom;
 
 /* A BatchNorm whose normalisation is applied/inverted inside another kernel.
- * mode 0: absent.  mode 1: batch statistics from `sums` (train).  mode 2: running stats (eval). */
+ * mode 0: absent.  mode 1: batch statistics from `sums` (train).  mode 2: running stats (eval).
+ * mode 3 (relu_bn of mopoe_conv_dgrad* only): as mode 1, but the tensor passed as `xin` is the ACTIVATION
+ *         y = relu(bn(x)) instead of x: the ReLU mask is [y > 0] and xhat = (y - beta) / gamma where it is set. */
 typedef struct {
   const double* sums;    /* [2*C] sum, sumsq over `count` rows (mode 1) */
   const float* gamma;    /* [C] */
@@ -275,6 +277,27 @@ int mopoe_token_logprob_rows(const float* logp, const float* ids, int64_t rows, 
  * Replaces mopoe_token_nll_bwd (a memset + scatter of a [rows, V] tensor) followed by mopoe_logsoftmax_bwd. */
 int mopoe_token_softmax_grad(const float* logp, const float* ids, const float* g, int64_t rows, int32_t V, float norm,
                              void* dx, int32_t dx_is_bf16, void* stream);
+/* The FRONT of a residual block, bn1 -> relu -> conv1 (1x1) -> dropout -> bn2 -> relu (reference ResidualBlocks.py:84-97,118-131;
+ * 1-D :20-33,51-65), as streaming kernels that never write d1 = drop1(conv1(.)) (csrc/pointwise.hip; bf16 family, C = 64,
+ * dropout mask absent or per (sample, channel) with rows_per_sample % 32 == 0; x, a2, dh2, dh1: [rows, C] bf16; w1: conv1's
+ * packed weight [C][C] (bf16 copy); bias [C] or NULL):
+ *   mopoe_block_front_stats_bf16   stats_d1[2][C] += {sum, sumsq} of d1 (rounded to bf16 as if stored)       reads x
+ *   mopoe_block_front_apply_bf16   a2 = relu(bn2(d1)), d1 recomputed bit for bit                             reads x, writes a2
+ *   mopoe_block_front_bwd_bf16     dh2 = gradient of bn2's output with its ReLU mask applied and sums2 = {sum dh2, sum dh2 xhat2}
+ *                                  (what mopoe_conv_dgrad_bf16 with relu_bn mode 3 / xin = a2 produces) ->
+ *                                  dh1 = [relu(bn1(x)) > 0] * (dc1 W1^T) with dc1 = mask * bn2-backward(dh2), rounded to bf16;
+ *                                  sums1[2][C] += {sum dh1, sum dh1 xhat1}; dw1[C][C] += relu(bn1(x))^T dc1; dbias[C] += colsum(dc1);
+ *                                  dgamma2[C] = sums2[1], dbeta2[C] = sums2[0] (bn2's affine gradients; both optional)
+ * replace mopoe_conv_fwd_bf16 (1x1) + mopoe_bn_relu_apply_bf16 and mopoe_bn_bwd_apply_bf16 + mopoe_conv_dgrad_bf16 (1x1) +
+ * mopoe_conv_wgrad_bf16 (1x1): 6 passes over [rows, C] instead of 12.  The gradients of bn2's affine parameters are sums2 itself. */
+int mopoe_block_front_stats_bf16(const uint16_t* x, const uint16_t* w1, const float* bias, int64_t rows, int32_t C,
+                                 const mopoe_bn_ref* bn1, const mopoe_mask_ref* mask1, double* stats_d1, void* stream);
+int mopoe_block_front_apply_bf16(const uint16_t* x, const uint16_t* w1, const float* bias, uint16_t* a2, int64_t rows, int32_t C,
+                                 const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, void* stream);
+int mopoe_block_front_bwd_bf16(const uint16_t* x, const uint16_t* dh2, const uint16_t* w1, const float* bias, uint16_t* dh1,
+                               int64_t rows, int32_t C, const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2,
+                               const mopoe_mask_ref* mask1, const double* sums2, double* sums1, float* dw1, float* dbias,
+                               float* dgamma2, float* dbeta2, void* stream);
 /* The vocabulary head WITHOUT a materialised log-softmax (reference word_encoding/DataGeneratorText.py:64-67,76-77: Conv1d k1
  * -> LogSoftmax; mimic/modalities/MimicText.py:37-40: one_hot x log-probabilities; Modality.py:25-30).  The head GEMM writes
  * the LOGITS [rows, V] once in the family's storage type (is_bf16: uint16 bf16 patterns, else float); V a multiple of 8
@@ -399,7 +422,7 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec
  *   60..74 gather_gemm_bf16_kernel: tile * 3 + (spec - 1)   (tiles 0..4 of the bf16 family)
  *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
-#define MOPOE_PROF_KINDS 124
+#define MOPOE_PROF_KINDS 127
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

@@ -24,7 +24,7 @@ __device__ __forceinline__ BnC bn_coef(const mopoe_bn_ref& b, int c) {
   r.mean = 0.f; r.rstd = 1.f; r.scale = 1.f; r.shift = 0.f;
   return r;
 #endif
-  if (b.mode == 1) {
+  if (b.mode == 1 || b.mode == 3) {
     const double m = b.sums[c] * b.inv_count;
     double v = b.sums[b.C + c] * b.inv_count - m * m;
     v = v < 0.0 ? 0.0 : v;
@@ -37,6 +37,17 @@ __device__ __forceinline__ BnC bn_coef(const mopoe_bn_ref& b, int c) {
   const float g = b.gamma[c];
   r.scale = g * r.rstd;
   r.shift = b.beta[c] - r.mean * r.scale;
+  if (b.mode == 3) {
+    // the tensor that will be read is the ACTIVATION y = relu(scale * x + shift) of this (batch-statistics) BatchNorm, not x
+    // (conv2's input gradient when the block front is recomputed, pointwise.hip): [y > 0] is the ReLU mask and
+    // xhat = (y - beta) / gamma wherever the mask is set -- the only places the masked gradient looks at xhat
+    BnC y;
+    y.mean = b.beta[c];
+    y.rstd = g != 0.f ? 1.0f / g : 0.f;
+    y.scale = 1.f;
+    y.shift = 0.f;
+    return y;
+  }
   return r;
 }
 
@@ -97,7 +108,7 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 //   fp32 gather, LDS-DMA: 104 + (tile - 12) * 3 + (spec - 1)                       kinds 104..115
 //   fp32 wgrad, LDS-DMA:  116 + (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)         kinds 116..119
 enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44,
-       PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_BF16_GLDS = 80, PROF_BF16_GLDS_X = 94, PROF_BF16_WGRAD_GLDS = 100, PROF_F32_GLDS = 104, PROF_F32_WGRAD_GLDS = 116, PROF_BF16_WGRAD_GLDS_MERGE = 120, PROF_BF16_WGRAD_PARITY = 122, PROF_NKINDS = MOPOE_PROF_KINDS };
+       PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_BF16_GLDS = 80, PROF_BF16_GLDS_X = 94, PROF_BF16_WGRAD_GLDS = 100, PROF_F32_GLDS = 104, PROF_F32_WGRAD_GLDS = 116, PROF_BF16_WGRAD_GLDS_MERGE = 120, PROF_BF16_WGRAD_PARITY = 122, PROF_PW_FRONT = 124, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {
   hipStream_t stream;
   int slot;

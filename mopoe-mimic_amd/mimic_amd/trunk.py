@@ -198,7 +198,15 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         st_s = arena.take(g2.Cout)
         sconv, sbn = p.short[0], p.short[1]
         s = lane.run(lambda: ops.conv_fwd(x, wsel(sconv), g2, bias=sconv.bias, out_stats=st_s), x)
-        d1 = ops.conv_fwd(x, wsel(p.conv1), g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
+        # the block's front as streaming kernels (csrc/pointwise.hip) where they exist: d1 is never written -- one pass over x for
+        # its statistics (train), one that recomputes it and writes a2 = relu(bn2(d1)); the backward recomputes it once more
+        front = _materialize(g2, x) and ops.block_front_supported(x, g1, mask1)
+        if front:
+            if training:
+                ops.block_front_stats(x, wsel(p.conv1), p.conv1.bias, bn1, mask1, st_d1)
+            d1 = None
+        else:
+            d1 = ops.conv_fwd(x, wsel(p.conv1), g1, bn_in=bn1, bias=p.conv1.bias, mask=mask1, out_stats=st_d1)
         bn2 = _bn(p.bn2, training, st_d1, rows_in)
         if training:
             running.append((st_d1, p.bn2, rows_in))
@@ -212,9 +220,12 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
             running.append((st_s, sbn, rows_out))
         st_out = arena.take(g2.Cout)
         # conv2's operand relu(bn2(d1)): applied on the operand load, or written out once (a2) and taken as it lies
-        a2 = ops.bn_relu_apply(d1, bn2) if _materialize(g2, d1) else None
+        if front:
+            a2 = ops.block_front_apply(x, wsel(p.conv1), p.conv1.bias, bn1, bn2, mask1)
+        else:
+            a2 = ops.bn_relu_apply(d1, bn2) if _materialize(g2, d1) else None
         op2, bn_in2 = (d1, bn2) if a2 is None else (a2, None)
-        if FUSE_MIX and ops.conv_mix_supported(d1, g2):
+        if FUSE_MIX and ops.conv_mix_supported(x, g2):
             out = ops.conv_fwd(op2, wsel(p.conv2), g2, bn_in=bn_in2, bias=p.conv2.bias, mask=mask2, mix=(s, bns), out_stats=st_out)
         else:
             m = ops.conv_fwd(op2, wsel(p.conv2), g2, bn_in=bn_in2, bias=p.conv2.bias, mask=mask2)
@@ -289,9 +300,15 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                        want_colsum_dm=has_bias, want_colsum_ds=True,
                                                        small=take_f(4, g2.Cout))
         sums2 = take_d(g1.Cout)
-        dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
-        w2, ws_ = take_w(g2), take_w(g2)
         a2 = sv.get("a2")
+        front = d1 is None      # (the forward ran the streaming front: d1 was never written)
+        if front:
+            # conv2's input gradient reads its ReLU mask and x-hat off a2 = relu(bn2(d1)) (mopoe_bn_ref mode 3)
+            bn2y = Bn(bn2.gamma, bn2.beta, 3, sums=bn2.sums, count=bn2.count, eps=bn2.eps)
+            dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2y, xin=a2, bwd_sums=sums2)
+        else:
+            dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2, xin=d1, bwd_sums=sums2)
+        w2, ws_ = take_w(g2), take_w(g2)
         if a2 is None:
             grads[f"{n}.conv2.weight"] = lane.run(lambda: ops.conv_wgrad(d1, dm, g2, bn_in=bn2, out=w2), d1, dm)
         else:
@@ -301,13 +318,25 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
         grads[f"{n}.{p.short_name}.0.bias"] = cds
         grads[f"{n}.{p.short_name}.1.weight"] = dgs
         grads[f"{n}.{p.short_name}.1.bias"] = dbs
-        dc1, dg2, db2, cdc1 = ops.bn_bwd_apply(dh2, d1, bn2, sums2, mask=sv["mask1"], want_colsum=has_bias,
-                                               small=take_f(3, g1.Cin))
-        grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
-        sums1 = take_d(g1.Cin)
-        dh1 = ops.conv_dgrad(dc1, wsel(p.conv1), g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
-        w1 = take_w(g1)
-        grads[f"{n}.conv1.weight"] = lane.run(lambda: ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=w1), x, dc1)
+        if front:
+            # bn2's backward, conv1's input and weight gradients and bn1's two backward sums in ONE pass over (x, dh2): d1 is
+            # recomputed, dc1 lives in registers (csrc/pointwise.hip: pw_front_bwd)
+            small = take_f(3, g1.Cin)
+            sums1 = take_d(g1.Cin)
+            w1 = take_w(g1)
+            dh1 = ops.block_front_bwd(x, dh2, wsel(p.conv1), p.conv1.bias, bn1, bn2, sv["mask1"], sums2, sums1, w1,
+                                      dbias=small[2] if has_bias else None, dgamma2=small[0], dbeta2=small[1])
+            grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = small[0], small[1]
+            grads[f"{n}.conv1.weight"] = w1
+            cdc1 = small[2]
+        else:
+            dc1, dg2, db2, cdc1 = ops.bn_bwd_apply(dh2, d1, bn2, sums2, mask=sv["mask1"], want_colsum=has_bias,
+                                                   small=take_f(3, g1.Cin))
+            grads[f"{n}.bn2.weight"], grads[f"{n}.bn2.bias"] = dg2, db2
+            sums1 = take_d(g1.Cin)
+            dh1 = ops.conv_dgrad(dc1, wsel(p.conv1), g1, relu_bn=bn1, xin=x, bwd_sums=sums1)
+            w1 = take_w(g1)
+            grads[f"{n}.conv1.weight"] = lane.run(lambda: ops.conv_wgrad(x, dc1, g1, bn_in=bn1, out=w1), x, dc1)
         if has_bias:
             grads[f"{n}.conv2.bias"] = cdm
             grads[f"{n}.conv1.bias"] = cdc1

@@ -390,6 +390,82 @@ def test_block_glue_bf16(rows, c):
     check("colsum", ops.colsum(sd), TB.colsum(s), rtol=1e-4, atol_rel=1e-4)
 
 
+@pytest.mark.parametrize("n,rps,drop", [(3, 64, True), (2, 1024, False), (5, 32, True), (1, 4096, True)])
+def test_block_front_streaming_kernels_bf16(n, rps, drop):
+    """csrc/pointwise.hip (round 4): the front of a residual block -- bn1 -> relu -> conv1 (1x1, 64 channels) -> Dropout2d -> bn2
+    -> relu -- without ever writing d1: statistics pass, a2 pass and the fused backward (bn2 backward + conv1 input / weight
+    gradients + bn1's backward sums) against the emulation, which composes exactly the ops these kernels replace; then the
+    replaced HIP ops themselves (conv_fwd + bn_relu_apply / bn_bwd_apply + conv_dgrad + conv_wgrad) on the same inputs."""
+    c, rows = 64, n * rps
+    gen = torch.Generator().manual_seed(n * 1000 + rps)
+    x = torch.randn(rows, c, generator=gen).to(BF).view(n, rps, 1, c)
+    w1 = (torch.randn(1, c, c, generator=gen) / 8).to(BF)
+    bias = 0.1 * torch.randn(c, generator=gen)
+    bn1 = make_bn(c, rows, 1, gen, x.float())
+    mask = Mask((torch.rand(n, c, generator=gen) < 0.5).float() * 2, 1, rps) if drop else None
+    g1 = Geom(n, rps, 1, rps, 1, c, c, 1, 1, 1, 1, 0, 0, False)
+    assert ops.block_front_supported(x.to(DEV), g1, to_dev(mask))
+    xd, wd, bd, bn1d, md = x.to(DEV), w1.to(DEV), bias.to(DEV), to_dev(bn1), to_dev(mask)
+    # statistics of d1
+    st_ref, st = torch.zeros(2, c, dtype=torch.float64), torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    TB.block_front_stats(x, w1, bias, bn1, mask, st_ref)
+    ops.block_front_stats(xd, wd, bd, bn1d, md, st)
+    check("front/stats", st, st_ref, rtol=2e-3, atol_rel=2e-3)
+    # ... which equal those of the conv kernel that used to write d1
+    st_old = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    d1_old = ops.conv_fwd(xd, wd, g1, bn_in=bn1d, bias=bd, mask=md, out_stats=st_old)
+    check("front/stats_vs_conv_fwd", st, st_old, rtol=2e-3, atol_rel=2e-3)
+    bn2 = Bn(torch.rand(c, generator=gen) + 0.5, 0.1 * torch.randn(c, generator=gen), 1, st_ref.clone(), rows)
+    bn2d = to_dev(bn2)
+    a2_ref = TB.block_front_apply(x, w1, bias, bn1, bn2, mask)
+    a2 = ops.block_front_apply(xd, wd, bd, bn1d, bn2d, md)
+    # (two rounding steps between the sums and a2: d1 is rounded to bf16, then relu(bn2(d1)) is -- a d1 that lands next to a
+    # rounding boundary may round the other way on the two sides, which moves a2 by up to one more step)
+    check("front/a2", a2.float(), a2_ref.float(), rtol=2.5 * ULP, atol_rel=2e-3)
+    check("front/a2_vs_bn_relu_apply", a2.float(), ops.bn_relu_apply(d1_old, bn2d).float(), rtol=2.5 * ULP, atol_rel=2e-3)
+    # backward
+    dh2 = (torch.randn(rows, c, generator=gen) * (a2_ref.view(rows, c).float() > 0)).to(BF).view(x.shape)
+    mean2, rstd2, _, _ = TB.bn_coef(bn2)
+    d1_ref = TB._front_d1(x, w1, bias, bn1, mask)[1]
+    sums2 = torch.stack([dh2.float().reshape(rows, c).double().sum(0),
+                         (dh2.float() * ((d1_ref - mean2) * rstd2)).reshape(rows, c).double().sum(0)])
+    out_ref = dict(s1=torch.zeros(2, c, dtype=torch.float64), dw=torch.zeros(1, c, c), db=torch.zeros(c), dg=torch.zeros(c), dbt=torch.zeros(c))
+    dh1_ref = TB.block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask, sums2, out_ref["s1"], out_ref["dw"], out_ref["db"], out_ref["dg"], out_ref["dbt"])
+    s1 = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    dw, db, dg, dbt = (torch.zeros(1, c, c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV))
+    dh1 = ops.block_front_bwd(xd, dh2.to(DEV), wd, bd, bn1d, bn2d, md, sums2.to(DEV), s1, dw, db, dg, dbt)
+    check("front/dh1", dh1.float(), dh1_ref.float(), rtol=2.5 * ULP, atol_rel=4e-3)
+    check("front/sums1", s1, out_ref["s1"], rtol=5e-3, atol_rel=5e-3)
+    check("front/dw1", dw, out_ref["dw"], rtol=2e-3, atol_rel=2e-3)
+    # (the column sums of a BatchNorm backward are analytically zero: what is left is the rounding of the stored dc1, so the
+    # bound is one rounding step of an element times sqrt(rows), not a fraction of the sum)
+    dc1_scale = max(out_ref["dw"].abs().max().item() / max(rows ** 0.5, 1.0), 1e-3)
+    noise = ULP * float(dh2.float().abs().max()) * float((bn2.gamma * TB.bn_coef(bn2)[1]).abs().max()) * rows ** 0.5 * 2
+    assert (db.cpu() - out_ref["db"]).abs().max().item() <= noise, ((db.cpu() - out_ref["db"]).abs().max().item(), noise)
+    check("front/dgamma2", dg, out_ref["dg"], rtol=1e-6, atol_rel=1e-6)
+    check("front/dbeta2", dbt, out_ref["dbt"], rtol=1e-6, atol_rel=1e-6)
+    # the ops it replaces, on the same inputs: bn_bwd_apply -> conv_dgrad (+ bn1 sums) -> conv_wgrad
+    dc1_old, _, _, cdc1_old = ops.bn_bwd_apply(dh2.to(DEV), d1_old, bn2d, sums2.to(DEV), mask=md, want_colsum=True)
+    s1_old = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    dh1_old = ops.conv_dgrad(dc1_old, wd, g1, relu_bn=bn1d, xin=xd, bwd_sums=s1_old)
+    check("front/dh1_vs_old_ops", dh1.float(), dh1_old.float(), rtol=2.5 * ULP, atol_rel=4e-3)
+    check("front/sums1_vs_old_ops", s1, s1_old, rtol=5e-3, atol_rel=5e-3)
+    check("front/dw1_vs_old_ops", dw, ops.conv_wgrad(xd, dc1_old, g1, bn_in=bn1d), rtol=2e-3, atol_rel=2e-3)
+    assert (db - cdc1_old).abs().max().item() <= noise, ((db - cdc1_old).abs().max().item(), noise)
+    # conv2's input gradient with its ReLU mask / x-hat taken from a2 (bn mode 3) == from d1 (mode 1)
+    g2 = Geom(n, 1, rps // 2, 1, rps, c, 128, 1, 4, 1, 2, 0, 1, False) if rps % 2 == 0 else None
+    if g2 is not None:
+        w2 = (torch.randn(g2.taps, c, 128, generator=gen) / 16).to(BF).to(DEV)
+        dm = torch.randn(g2.out_shape, generator=gen).to(BF).to(DEV)
+        xa = d1_old.view(g2.in_shape)
+        sa, sb = torch.zeros(2, c, dtype=torch.float64, device=DEV), torch.zeros(2, c, dtype=torch.float64, device=DEV)
+        ga = ops.conv_dgrad(dm, w2, g2, relu_bn=bn2d, xin=xa, bwd_sums=sa)
+        bn2y = Bn(bn2d.gamma, bn2d.beta, 3, sums=bn2d.sums, count=bn2d.count)
+        gb = ops.conv_dgrad(dm, w2, g2, relu_bn=bn2y, xin=a2.view(g2.in_shape), bwd_sums=sb)
+        check16("front/conv2_dgrad_mask_from_a2", gb, ga.cpu())
+        check("front/conv2_dgrad_sums_from_a2", sb, sa, rtol=2e-2, atol_rel=2e-2)    # (x-hat through the bf16-rounded a2)
+
+
 def test_embedding_bf16():
     gen = torch.Generator().manual_seed(3)
     table = torch.randn(101, 64, generator=gen)

@@ -22,7 +22,8 @@ OP_NAMES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "block_out_fwd", "bn_relu_ap
             "laplace_nll_bwd", "logsoftmax_fwd", "logsoftmax_bwd", "token_nll_fwd", "token_nll_bwd",
             "embedding_fwd", "embedding_bwd", "laplace_logprob_rows", "token_logprob_rows", "dense_nll_fwd", "dense_nll_bwd",
             "dense_logprob_rows", "conv_mix_supported", "token_softmax_grad", "adam_step", "lse_rows",
-            "token_nll_logits_fwd", "token_softmax_grad_logits"]
+            "token_nll_logits_fwd", "token_softmax_grad_logits", "block_front_stats", "block_front_apply", "block_front_bwd",
+            "block_front_supported"]
 
 
 def install(monkeypatch):
@@ -35,7 +36,11 @@ def install(monkeypatch):
 
 # ---- helpers -----------------------------------------------------------------------------------
 def bn_coef(bn: Bn):
-    """-> mean, rstd, scale, shift (float32 [C])"""
+    """-> mean, rstd, scale, shift (float32 [C]).  mode 3 (the tensor read is y = relu(bn(x)), csrc/common.hpp: bn_coef):
+    mean' = beta, rstd' = 1 / gamma, scale' = 1, shift' = 0"""
+    if bn.mode == 3:
+        g = bn.gamma
+        return bn.beta, torch.where(g != 0, 1.0 / g, torch.zeros_like(g)), torch.ones_like(g), torch.zeros_like(g)
     if bn.mode == 1:
         mean = bn.sums[0] / bn.count
         var = bn.sums[1] / bn.count - mean * mean
@@ -196,6 +201,60 @@ def bn_relu_apply(x, bn):
     dt = x.dtype
     _, _, scale, shift = bn_coef(bn)
     return _store(torch.relu(_f(x) * scale + shift), dt)[1]
+
+
+def _front_d1(x, w1, bias, bn1, mask1):
+    """d1 = mask1 * (conv1(relu(bn1(x))) + bias), rounded to its storage type (bf16) -- what round 3 kept in HBM"""
+    h1 = _act16(x, bn1)                                    # bf16-rounded operand (as a float tensor)
+    c = x.shape[-1]
+    d = h1.reshape(-1, c) @ _f(w1).reshape(c, c)
+    if bias is not None:
+        d = d + bias
+    d = d.view(x.shape)
+    mm = _mask_mult(d, mask1)
+    if mm is not None:
+        d = d * mm
+    return h1, _q16(d)
+
+
+def block_front_stats(x, w1, bias, bn1, mask1, out_stats):
+    _, d1 = _front_d1(x, w1, bias, bn1, mask1)
+    _accum(out_stats, d1)
+    return out_stats
+
+
+def block_front_apply(x, w1, bias, bn1, bn2, mask1):
+    _, d1 = _front_d1(x, w1, bias, bn1, mask1)
+    _, _, scale, shift = bn_coef(bn2)
+    return _q16(torch.relu(d1 * scale + shift)).to(x.dtype)
+
+
+def block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask1, sums2, sums1, dw1, dbias=None, dgamma2=None, dbeta2=None):
+    c = x.shape[-1]
+    h1, d1 = _front_d1(x, w1, bias, bn1, mask1)
+    dc1 = _bn_bwd(_f(dh2), d1, bn2, sums2)
+    mm = _mask_mult(dc1, mask1)
+    if mm is not None:
+        dc1 = dc1 * mm
+    dc1 = _q16(dc1)
+    dh1 = (dc1.reshape(-1, c) @ _f(w1).reshape(c, c).t()).view(x.shape) * (h1 > 0).to(dc1.dtype)
+    dh1 = _q16(dh1)
+    mean1, rstd1, _, _ = bn_coef(bn1)
+    xhat1 = (_f(x) - mean1) * rstd1
+    sums1[0] += dh1.reshape(-1, c).double().sum(0)
+    sums1[1] += (dh1 * xhat1).reshape(-1, c).double().sum(0)
+    dw1 += (h1.reshape(-1, c).t() @ dc1.reshape(-1, c)).view(dw1.shape)
+    if dbias is not None:
+        dbias += dc1.reshape(-1, c).sum(0)
+    if dgamma2 is not None:
+        dgamma2.copy_(sums2[1].float())
+        dbeta2.copy_(sums2[0].float())
+    return dh1.to(x.dtype)
+
+
+def block_front_supported(x, g1, mask1):
+    return (real_ops.BLOCK_FRONT and x.dtype == BF16 and g1.Cin == 64 and g1.Cout == 64 and g1.taps == 1
+            and (x.numel() // x.shape[-1]) % 32 == 0 and (mask1 is None or (mask1.kind == 1 and mask1.rows_per_sample % 32 == 0)))
 
 
 def bn_bwd_reduce(g, s, bn_s, sums=None):
