@@ -302,10 +302,13 @@ __global__ __launch_bounds__(512, 2) void pw_front_bwd_bf16_kernel(const PwArgs 
   };
 
   const int stride = gridDim.x * NW;
-  for (int tile = blockIdx.x * NW + wave; tile < a.ntiles; tile += stride) {
-    u32x4 xr[NG], gr[NG];
-    load_rows(srdX, tile, xr);
-    load_rows(srdD, tile, gr);
+  int tile = blockIdx.x * NW + wave;
+  u32x4 xr[NG], gr[NG], xn[NG], gn[NG];
+  if (tile < a.ntiles) { load_rows(srdX, tile, xr); load_rows(srdD, tile, gr); }
+  for (; tile < a.ntiles; tile += stride) {
+    // the next tile's rows are requested before this tile's arithmetic: the wave's share of the HBM stream stays in flight
+    const bool more = tile + stride < a.ntiles;
+    if (more) { load_rows(srdX, tile + stride, xn); load_rows(srdD, tile + stride, gn); }
     const long row = (long)tile * 32 + p;
     const bool ok = row < a.R;
     const float* mrow = a.mask1.kind == 1 ? a.mask1.mask + ((long)tile * 32 / a.mask1.rows_per_sample) * C : nullptr;
@@ -452,6 +455,10 @@ __global__ __launch_bounds__(512, 2) void pw_front_bwd_bf16_kernel(const PwArgs 
       Sg += (double)sg;
       Sgx += (double)sgx;
     }
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < NG; ++s) { xr[s] = xn[s]; gr[s] = gn[s]; }
+    }
   }
 
   // ---- block reductions, then one set of atomics per block
@@ -513,9 +520,9 @@ static int pw_check(const char* what, const void* x, const void* W, int64_t rows
   return 0;
 }
 
-static int pw_grid(int ntiles) {
+static int pw_grid(int ntiles, int per_cu) {
   const int blocks = (ntiles + 7) / 8;
-  return blocks < 256 ? blocks : 256;       // one 8-wave block per CU, each wave walking its tiles
+  return blocks < 256 * per_cu ? blocks : 256 * per_cu;       // 8-wave blocks, each wave walking its tiles
 }
 
 }  // namespace mopoe
@@ -531,7 +538,7 @@ extern "C" int mopoe_block_front_stats_bf16(const uint16_t* x, const uint16_t* w
   a.x_bytes = (unsigned)((size_t)rows * C * 2);
   if (mask1) a.mask1 = *mask1;
   ProfScope prof((hipStream_t)stream, 2.0 * (double)rows * C * C, PROF_PW_FRONT, (double)rows * C * 2.0);
-  hipLaunchKernelGGL((pw_front_fwd_bf16_kernel<64, false>), dim3(pw_grid(a.ntiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((pw_front_fwd_bf16_kernel<64, false>), dim3(pw_grid(a.ntiles, 2)), dim3(512), 0, (hipStream_t)stream, a);
   return check_launch("block_front_stats_bf16");
 }
 
@@ -544,7 +551,7 @@ extern "C" int mopoe_block_front_apply_bf16(const uint16_t* x, const uint16_t* w
   a.x_bytes = (unsigned)((size_t)rows * C * 2);
   if (mask1) a.mask1 = *mask1;
   ProfScope prof((hipStream_t)stream, 2.0 * (double)rows * C * C, PROF_PW_FRONT + 1, (double)rows * C * 4.0);
-  hipLaunchKernelGGL((pw_front_fwd_bf16_kernel<64, true>), dim3(pw_grid(a.ntiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((pw_front_fwd_bf16_kernel<64, true>), dim3(pw_grid(a.ntiles, 2)), dim3(512), 0, (hipStream_t)stream, a);
   return check_launch("block_front_apply_bf16");
 }
 
@@ -562,6 +569,6 @@ extern "C" int mopoe_block_front_bwd_bf16(const uint16_t* x, const uint16_t* dh2
   a.x_bytes = (unsigned)((size_t)rows * C * 2);
   if (mask1) a.mask1 = *mask1;
   ProfScope prof((hipStream_t)stream, 6.0 * (double)rows * C * C, PROF_PW_FRONT + 2, (double)rows * C * 6.0);
-  hipLaunchKernelGGL((pw_front_bwd_bf16_kernel<64>), dim3(pw_grid(a.ntiles)), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((pw_front_bwd_bf16_kernel<64>), dim3(pw_grid(a.ntiles, 1)), dim3(512), 0, (hipStream_t)stream, a);
   return check_launch("block_front_bwd_bf16");
 }
