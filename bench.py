@@ -306,14 +306,20 @@ def main():
         # events would also time whatever runs beside it.  (profiles/ holds the rocprofv3 stats of both regimes.)
         from mimic_amd import lanes as _ln, trunk as _tr
         _ln.NET_STREAMS, _tr.WGRAD_SIDE_STREAM = False, False
-        run(2, start=args.warmup, eager=True)
-        torch.cuda.synchronize()
-        ops.prof_enable(True)
-        nprof = min(args.steps, 5)
-        run(nprof, start=args.warmup, eager=True)
-        torch.cuda.synchronize()
-        prof = ops.prof_collect()
-        ops.prof_enable(False)
+        # (on the stream the captured step was built on: the parameters' AccumulateGrad nodes were created under that stream
+        # during the set-up's eager steps and are kept alive; an eager backward on ANOTHER stream makes autograd warn about --
+        # and synchronise for -- the mismatch.  Inside the capture and the replays there is none: set-up, capture and replay
+        # all run on GraphedTrainStep.stream.)
+        prof_stream = graphed.stream if graphed is not None else torch.cuda.current_stream(device)
+        with torch.cuda.stream(prof_stream):
+            run(2, start=args.warmup, eager=True)
+            torch.cuda.synchronize()
+            ops.prof_enable(True)
+            nprof = min(args.steps, 5)
+            run(nprof, start=args.warmup, eager=True)
+            torch.cuda.synchronize()
+            prof = ops.prof_collect()
+            ops.prof_enable(False)
         name, (n, ms, fl, by) = max(prof.items(), key=lambda kv: kv[1][1])
         all_ms = sum(v[1] for v in prof.values())
         all_fl = sum(v[2] for v in prof.values())

@@ -100,14 +100,30 @@ size_t mopoe_conv_workspace_bytes(void);
 /* Launch plan of one conv op (NULL = the library's static heuristic).  Every plan computes the same sums in
  * a different association order; the host mirror times the candidates the first time it meets a
  * (op, geometry, fusion) triple during warm-up and keeps the fastest (mimic_amd/ops.py, MOPOE_AUTOTUNE).
- *   fwd / dgrad: tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 output tile
- *                      (0, 1, 3: 8 waves per block; 2, 4: 4 waves) | 5, 6 = tiles 2, 4 with a 32-deep K chunk
- *                      | 7 = 128x128 with 4 waves per block
- *                      | 8..11 = 128x128, 256x64, 64x64, 128x64 tiles of the LDS-free kernel (operands streamed from
- *                        global memory into the MFMA registers; needs channel counts that are multiples of 8)
- *                split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction (needs workspace)
- *   wgrad:       tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap)
- *                split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp) */
+ * fp32 family (mopoe_conv_fwd / _fwd_mix / _dgrad):
+ *   tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 output tile (0, 1, 3: 8 waves per block;
+ *          2, 4: 4 waves) | 5, 6 = tiles 2, 4 with a 32-deep K chunk (K channels % 32 == 0) | 7 = 128x128 with 4 waves
+ *          | 8..11 = 128x128, 256x64, 64x64, 128x64 tiles of the LDS-free kernel (operands streamed from global memory into the
+ *            MFMA registers; channel counts multiples of 8)
+ *          | 12..15 = 128x128, 128x64, 64x64, 256x128 on LDS-DMA (csrc/conv_gemm_glds.inc: buffer_load ... lds, 32-deep stages,
+ *            2-4 LDS buffers; K channels % 32 == 0, channel counts % 4 == 0; with BN -> ReLU on load: 12, 14, 15 only)
+ *   split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction, finished by the last-arriving block (needs workspace)
+ * fp32 weight gradient (mopoe_conv_wgrad):
+ *   tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap, register-staged, 16 pixels per chunk)
+ *          | 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per stage; channel counts % 4 == 0; 5 needs > 64 channels on both sides)
+ *   split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp)
+ * bf16 family (mopoe_conv_fwd_bf16 / _fwd_mix_bf16 / _dgrad_bf16):
+ *   tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 (register-staged, 32-deep K chunk)
+ *          | 5 = 128x128 (2 buffers) | 6 = 128x128 (3) | 7 = 256x128 (2) | 9 = 128x64 (2) | 10 = 128x64 (3) | 11 = 64x64 (4) on LDS-DMA
+ *            (csrc/conv_gemm_bf16_glds.inc: 64-deep stages; K channels % 64 == 0; with BN -> ReLU on load: 5, 7, 9, 11 only);
+ *            8 (256x128, 3 buffers) is refused: it spills registers
+ * bf16 weight gradient (mopoe_conv_wgrad_bf16):
+ *   tile  -1 auto | 0 = 128x128 | 2 = 64x64 (register-staged) | 5 = 128x128 (needs > 64 channels on both sides), 6 = 64x64 on LDS-DMA
+ *          | 7 = 128x128 with TWO taps per block on the gathered operand's side (that side has 64 channels; plain operand; even tap count)
+ *          | 8, 9 = FOUR taps (one parity class of a k4 s2 p1 kernel) per block, 64 gathered channels x 64 / 128 channels of the
+ *            small-grid operand (plain operand; small grid of whole 8 x 8 tiles; 9 needs a multiple of 128 channels there);
+ *            split = blocks sharing the pixel TILES
+ */
 typedef struct {
   int32_t tile;
   int32_t split;
@@ -421,7 +437,15 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   42..43 wgrad_gemm_kernel, scalar path: 128x128, 64x64
  *   44..59 direct_gemm_kernel: (tile - 8) * 4 + spec
  *   60..74 gather_gemm_bf16_kernel: tile * 3 + (spec - 1)   (tiles 0..4 of the bf16 family)
- *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0) */
+ *   75..78 wgrad_gemm_bf16_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)
+ *   80..93 gather_gemm_bf16_glds_kernel, plain operand: (tile - 5) * 2 + (input gradient ? 1 : 0)   (bf16 tiles 5..11)
+ *   94..98 gather_gemm_bf16_glds_kernel with BN+ReLU on load: tiles 5, 7, 9, 10, 11 -> 94..98
+ *   100..103 wgrad_gemm_bf16_glds_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)
+ *   104..115 gather_gemm_f32_glds_kernel: (tile - 12) * 3 + (spec - 1)   (fp32 tiles 12..15)
+ *   116..119 wgrad_gemm_f32_glds_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)
+ *   120..121 wgrad_gemm_bf16_glds_kernel, two taps per block (tile 7): gathered side = activations / gradient rows
+ *   122..123 wgrad_parity_bf16_kernel (tiles 8 / 9: four taps per block), S tile 64 / 128
+ *   124..126 pw_front_fwd_bf16_kernel<64, false> (statistics pass), <64, true> (a2 pass), pw_front_bwd_bf16_kernel<64> */
 #define MOPOE_PROF_KINDS 127
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
