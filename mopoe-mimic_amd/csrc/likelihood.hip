@@ -385,6 +385,16 @@ __global__ __launch_bounds__(256) void dense_logprob_rows_kernel(const float* lo
   if (threadIdx.x == 0) out[r] = (float)s;
 }
 
+// grid of a kernel that ends in finish_scalar(): every block adds to ONE double and bumps ONE counter -- same-address atomics
+// serialise at the memory side at ~18 ns each, so the grid is capped at one block per CU (round 4: laplace_nll_fwd ran 1024
+// blocks = ~35 us of atomic tail behind 8 us of streaming, on the critical path between the step's forward and backward)
+static int reduce_grid(long n, int per_thread) {
+  long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  return (int)blocks;
+}
+
 static int stream_grid(long n, int per_thread) {
   long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (blocks < 1) blocks = 1;
@@ -400,7 +410,7 @@ extern "C" int mopoe_laplace_nll_fwd(const float* x_hat, const float* x, int64_t
                                      double* ws, void* stream) {
   if (!x_hat || !x || !out || !ws || n <= 0 || scale <= 0.f || norm <= 0.f) { set_error("laplace_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
   const int vec = ((reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-  const int nb = stream_grid(n, 16);
+  const int nb = reduce_grid(n, 16);
   hipLaunchKernelGGL(laplace_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x_hat, x, (long)n, 1.0f / scale,
                      logf(2.0f * scale), 1.0f / norm, out, ws, nb, vec);
   return check_launch("laplace_nll_fwd");
@@ -417,7 +427,7 @@ extern "C" int mopoe_laplace_nll_bwd(const float* x_hat, const float* x, const f
 extern "C" int mopoe_dense_nll_fwd(const float* logp, const float* target, int64_t n, float norm, float* out, double* ws,
                                    void* stream) {
   if (!logp || !target || !out || !ws || n <= 0 || norm <= 0.f) { set_error("dense_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
-  const int nb = stream_grid(n, 16);
+  const int nb = reduce_grid(n, 16);
   hipLaunchKernelGGL(dense_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logp, target, (long)n, 1.0f / norm, out, ws, nb);
   return check_launch("dense_nll_fwd");
 }
@@ -493,7 +503,7 @@ extern "C" int mopoe_lse_rows(const void* logits, int32_t is_bf16, int64_t rows,
 extern "C" int mopoe_token_nll_logits_fwd(const void* logits, int32_t is_bf16, const float* lse, const float* ids, int64_t rows,
                                           int32_t V, float norm, float* out, double* ws, void* stream) {
   if (!logits || !lse || !ids || !out || !ws || rows <= 0 || V <= 0 || norm <= 0.f) { set_error("token_nll_logits_fwd: bad arguments"); return MOPOE_ERR_ARG; }
-  const int nb = stream_grid(rows, 1);
+  const int nb = reduce_grid(rows, 1);
   if (is_bf16) hipLaunchKernelGGL(token_nll_logits_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits,
                                   lse, ids, (long)rows, V, 1.0f / norm, out, ws, nb);
   else hipLaunchKernelGGL(token_nll_logits_fwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)logits, lse, ids,
@@ -519,7 +529,7 @@ extern "C" int mopoe_token_softmax_grad_logits(const void* logits, int32_t is_bf
 extern "C" int mopoe_token_nll_fwd(const float* logp, const float* ids, int64_t rows, int32_t V, float norm, float* out,
                                    double* ws, void* stream) {
   if (!logp || !ids || !out || !ws || rows <= 0 || V <= 0 || norm <= 0.f) { set_error("token_nll_fwd: bad arguments"); return MOPOE_ERR_ARG; }
-  const int nb = stream_grid(rows, 1);
+  const int nb = reduce_grid(rows, 1);
   hipLaunchKernelGGL(token_nll_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logp, ids, (long)rows, V,
                      1.0f / norm, out, ws, nb);
   return check_launch("token_nll_fwd");
