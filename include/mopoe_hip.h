@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 16
+#define MOPOE_ABI_VERSION 17
 
 /* error codes */
 #define MOPOE_OK 0
@@ -314,6 +314,14 @@ int mopoe_block_front_bwd_bf16(const uint16_t* x, const uint16_t* dh2, const uin
                                int64_t rows, int32_t C, const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2,
                                const mopoe_mask_ref* mask1, const double* sums2, double* sums1, float* dw1, float* dbias,
                                float* dgamma2, float* dbeta2, void* stream);
+/* the same three kernels of the fp32 family (v_mfma_f32_32x32x2_f32; x, a2, dh2, dh1 and w1 fp32) */
+int mopoe_block_front_stats(const float* x, const float* w1, const float* bias, int64_t rows, int32_t C,
+                            const mopoe_bn_ref* bn1, const mopoe_mask_ref* mask1, double* stats_d1, void* stream);
+int mopoe_block_front_apply(const float* x, const float* w1, const float* bias, float* a2, int64_t rows, int32_t C,
+                            const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, void* stream);
+int mopoe_block_front_bwd(const float* x, const float* dh2, const float* w1, const float* bias, float* dh1, int64_t rows, int32_t C,
+                          const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, const double* sums2,
+                          double* sums1, float* dw1, float* dbias, float* dgamma2, float* dbeta2, void* stream);
 /* The vocabulary head WITHOUT a materialised log-softmax (reference word_encoding/DataGeneratorText.py:64-67,76-77: Conv1d k1
  * -> LogSoftmax; mimic/modalities/MimicText.py:37-40: one_hot x log-probabilities; Modality.py:25-30).  The head GEMM writes
  * the LOGITS [rows, V] once in the family's storage type (is_bf16: uint16 bf16 patterns, else float); V a multiple of 8
@@ -445,8 +453,9 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   116..119 wgrad_gemm_f32_glds_kernel: (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)
  *   120..121 wgrad_gemm_bf16_glds_kernel, two taps per block (tile 7): gathered side = activations / gradient rows
  *   122..123 wgrad_parity_bf16_kernel (tiles 8 / 9: four taps per block), S tile 64 / 128
- *   124..126 pw_front_fwd_bf16_kernel<64, false> (statistics pass), <64, true> (a2 pass), pw_front_bwd_bf16_kernel<64> */
-#define MOPOE_PROF_KINDS 127
+ *   124..126 pw_front_fwd_bf16_kernel<64, false> (statistics pass), <64, true> (a2 pass), pw_front_bwd_bf16_kernel<64>
+ *   127..129 pw_front_fwd_f32_kernel<false>, <true>, pw_front_bwd_f32_kernel */
+#define MOPOE_PROF_KINDS 130
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

@@ -508,6 +508,366 @@ __global__ __launch_bounds__(512, 2) void pw_front_bwd_bf16_kernel(const PwArgs 
   }
 }
 
+// =====================================================================================================================
+// fp32 family (BASELINE configs #2, #4): the same three kernels on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums).
+//
+// Lane (p, h) owns, for g = 0..7, the 16-byte piece of pixel p's row that holds channels 8 g + 4 h + e (e = 0..3): 32 values,
+// value u = 4 g + e.  That IS the B operand of MFMA number u (k = h), and the accumulator of output tile t returns register
+// r = 4 q + e as channel 32 t + 8 q + 4 h + e, i.e. value u = 4 (4 t + q) + e of the same layout -- no row permutation needed.
+// A MFMA does 64 cycles of work for 2 k: a 64 x 64 product per 32 pixels is 64 MFMAs = 4096 cycles per wave, so with the
+// three products of the backward pass the matrix pipe and the HBM stream take about the same time (7.4 against 8.1 bytes per
+// clock and CU): these kernels run one wave per SIMD with the next tile's rows in flight, and 350 registers.
+// LDS patches are fp32 [32][64] (256-byte rows, 16-byte slot ^ (p & 7)); fragments of the weight gradient are plain
+// ds_read_b32 (lane = channel: no transposition instruction is needed in fp32).
+// =====================================================================================================================
+struct PwArgsF {
+  const float* x; const float* dh2; float* out; const float* W; const float* bias;
+  mopoe_bn_ref bn1, bn2;
+  mopoe_mask_ref mask1;
+  double* stats_d1; const double* sums2; double* sums1; float* dW; float* dbias; float* dgamma2; float* dbeta2;
+  long R; int ntiles; unsigned x_bytes;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256, 1) void pw_front_fwd_f32_kernel(const PwArgsF a) {
+  constexpr int C = 64, NP = 8, NT = 2, NW = 4;       // pieces per lane, output tiles, waves
+  constexpr int IMG_BYTES = NT * 8 * 1024;            // A operands: per tile 32 MFMAs = 8 groups of 4, 1 KB per group
+  constexpr int OFF_TAB = IMG_BYTES;                  // scale1, shift1, bias, scale2, shift2
+  constexpr int OFF_PATCH = OFF_TAB + 5 * C * 4;
+  constexpr int PATCH_BYTES = 32 * C * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[OFF_PATCH + (WRITE ? 0 : NW * PATCH_BYTES)];
+  float* const tab = reinterpret_cast<float*>(smem + OFF_TAB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  for (int c = tid; c < C; c += 256) {
+    const BnC k1 = bn_coef(a.bn1, c);
+    tab[c] = k1.scale; tab[C + c] = k1.shift;
+    tab[2 * C + c] = a.bias ? a.bias[c] : 0.f;
+    if (WRITE) { const BnC k2 = bn_coef(a.bn2, c); tab[3 * C + c] = k2.scale; tab[4 * C + c] = k2.shift; }
+  }
+  // group (t, gq) = MFMAs u = 4 gq .. 4 gq + 3 of tile t; lane (m, kh) holds W[ci = 8 gq + 4 kh + e][co = 32 t + m], e = 0..3
+  for (int idx = tid; idx < NT * 8 * 64; idx += 256) {
+    const int grp = idx >> 6, ln = idx & 63, t = grp >> 3, gq = grp & 7, m = ln & 31, kh = ln >> 5;
+    float4 w;
+    const int ci = 8 * gq + 4 * kh, co = 32 * t + m;
+    w.x = a.W[(ci + 0) * C + co]; w.y = a.W[(ci + 1) * C + co]; w.z = a.W[(ci + 2) * C + co]; w.w = a.W[(ci + 3) * C + co];
+    *reinterpret_cast<float4*>(smem + idx * 16) = w;
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  unsigned char* const patch = smem + OFF_PATCH + (WRITE ? 0 : wave * PATCH_BYTES);
+  double S1 = 0.0, S2 = 0.0;
+  auto load_x = [&](int tile, float4 (&xr)[NP]) {
+    const long row = (long)tile * 32 + p;
+    const unsigned base = row < a.R ? (unsigned)(row * C + 4 * h) * 4u : OOB;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) xr[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srdX, base, (unsigned)(32 * g), 0));
+  };
+  const int stride = gridDim.x * NW;
+  int tile = blockIdx.x * NW + wave;
+  float4 xc[NP], xn[NP];
+  if (tile < a.ntiles) load_x(tile, xc);
+  for (; tile < a.ntiles; tile += stride) {
+    const bool more = tile + stride < a.ntiles;
+    if (more) load_x(tile + stride, xn);
+    const long row = (long)tile * 32 + p;
+    const bool ok = row < a.R;
+    const float* mrow = a.mask1.kind == 1 ? a.mask1.mask + ((long)tile * 32 / a.mask1.rows_per_sample) * C : nullptr;
+    float hv[32];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int c0 = 8 * g + 4 * h;
+      const float4 sc = *reinterpret_cast<const float4*>(&tab[c0]), sh = *reinterpret_cast<const float4*>(&tab[C + c0]);
+      hv[4 * g + 0] = ok ? fmaxf(fmaf(xc[g].x, sc.x, sh.x), 0.f) : 0.f;
+      hv[4 * g + 1] = ok ? fmaxf(fmaf(xc[g].y, sc.y, sh.y), 0.f) : 0.f;
+      hv[4 * g + 2] = ok ? fmaxf(fmaf(xc[g].z, sc.z, sh.z), 0.f) : 0.f;
+      hv[4 * g + 3] = ok ? fmaxf(fmaf(xc[g].w, sc.w, sh.w), 0.f) : 0.f;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 w = *reinterpret_cast<const float4*>(smem + ((t * 8 + gq) * 64 + lane) * 16);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, hv[4 * gq + 0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, hv[4 * gq + 1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, hv[4 * gq + 2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, hv[4 * gq + 3], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {       // piece g = 4 t + q: registers 4 q .. 4 q + 3 of tile t
+      const int c0 = 8 * g + 4 * h, t = g >> 2, q = g & 3;
+      const float4 bb = *reinterpret_cast<const float4*>(&tab[2 * C + c0]);
+      float4 d;
+      d.x = acc[t][4 * q + 0] + bb.x; d.y = acc[t][4 * q + 1] + bb.y; d.z = acc[t][4 * q + 2] + bb.z; d.w = acc[t][4 * q + 3] + bb.w;
+      if (mrow) { const float4 m = *reinterpret_cast<const float4*>(mrow + c0); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+      if (!WRITE) {
+        if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(patch + p * 256 + (((2 * g + h) ^ (p & 7)) << 4)) = d;
+      } else {
+        const float4 s2 = *reinterpret_cast<const float4*>(&tab[3 * C + c0]), t2 = *reinterpret_cast<const float4*>(&tab[4 * C + c0]);
+        float4 o;
+        o.x = fmaxf(fmaf(d.x, s2.x, t2.x), 0.f); o.y = fmaxf(fmaf(d.y, s2.y, t2.y), 0.f);
+        o.z = fmaxf(fmaf(d.z, s2.z, t2.z), 0.f); o.w = fmaxf(fmaf(d.w, s2.w, t2.w), 0.f);
+        if (ok) *reinterpret_cast<float4*>(a.out + row * C + c0) = o;
+      }
+    }
+    if (!WRITE) {
+      const int c = lane;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+      for (int pp = 0; pp < 32; ++pp) {
+        const float v = *reinterpret_cast<const float*>(patch + pp * 256 + ((((c >> 2) ^ (pp & 7)) << 4) | ((c & 3) << 2)));
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+      S1 += (double)s1;
+      S2 += (double)s2;
+    }
+    if (more) {
+#pragma unroll
+      for (int g = 0; g < NP; ++g) xc[g] = xn[g];
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);
+    red[(wave * 2 + 0) * C + lane] = S1;
+    red[(wave * 2 + 1) * C + lane] = S2;
+    __syncthreads();
+    if (tid < 2 * C) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(w * 2 + tid / C) * C + tid % C];
+      atomic_add_f64(a.stats_d1 + tid, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void pw_front_bwd_f32_kernel(const PwArgsF a) {
+  constexpr int C = 64, NP = 8, NT = 2, NW = 4;
+  constexpr int IMG_BYTES = NT * 8 * 1024;
+  constexpr int OFF_IMG2 = IMG_BYTES;
+  constexpr int OFF_TAB = 2 * IMG_BYTES;              // scale1, shift1, bias, ga, gb, gc, xh_a, xh_b: 8 x C floats
+  constexpr int OFF_PATCH = OFF_TAB + 8 * C * 4;
+  constexpr int PATCH_BYTES = 32 * C * 4;             // per wave: h1, dc1 / dh1
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[OFF_PATCH + NW * 2 * PATCH_BYTES];
+  float* const tab = reinterpret_cast<float*>(smem + OFF_TAB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  for (int c = tid; c < C; c += 256) {
+    const BnC k1 = bn_coef(a.bn1, c);
+    const BnC k2 = bn_coef(a.bn2, c);
+    tab[c] = k1.scale; tab[C + c] = k1.shift;
+    tab[2 * C + c] = a.bias ? a.bias[c] : 0.f;
+    const double c1 = a.sums2[c] * a.bn2.inv_count, c2 = a.sums2[C + c] * a.bn2.inv_count;
+    const float ga = k2.scale;
+    tab[3 * C + c] = ga;
+    tab[4 * C + c] = (float)(-(double)ga * c1 + (double)ga * c2 * (double)k2.rstd * (double)k2.mean);
+    tab[5 * C + c] = (float)(-(double)ga * c2 * (double)k2.rstd);
+    // xhat1 = (x - mean1) rstd1 = (h1 - beta1) / gamma1 wherever h1 > 0 (the only places dh1 is not zero): xh_a h1 + xh_b
+    const float g1 = a.bn1.gamma[c], b1 = a.bn1.beta[c];
+    tab[6 * C + c] = g1 != 0.f ? 1.0f / g1 : 0.f;
+    tab[7 * C + c] = g1 != 0.f ? -b1 / g1 : 0.f;
+  }
+  for (int idx = tid; idx < NT * 8 * 64; idx += 256) {
+    const int grp = idx >> 6, ln = idx & 63, t = grp >> 3, gq = grp & 7, m = ln & 31, kh = ln >> 5;
+    const int k0 = 8 * gq + 4 * kh, mm = 32 * t + m;
+    float4 w1, w2;      // first product: W[ci = k0 + e][co = mm]; second: W[ci = mm][co = k0 + e]
+    w1.x = a.W[(k0 + 0) * C + mm]; w1.y = a.W[(k0 + 1) * C + mm]; w1.z = a.W[(k0 + 2) * C + mm]; w1.w = a.W[(k0 + 3) * C + mm];
+    w2 = *reinterpret_cast<const float4*>(a.W + mm * C + k0);
+    *reinterpret_cast<float4*>(smem + idx * 16) = w1;
+    *reinterpret_cast<float4*>(smem + OFF_IMG2 + idx * 16) = w2;
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dh2, 0, (int)a.x_bytes, 0x00020000);
+  unsigned char* const pH = smem + OFF_PATCH + wave * 2 * PATCH_BYTES;
+  unsigned char* const pD = pH + PATCH_BYTES;
+  f32x16 wacc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wacc[i][j][r] = 0.f;
+  double Sg = 0.0, Sgx = 0.0, Sb = 0.0;
+  auto load_rows = [&](const __amdgpu_buffer_rsrc_t& srd, int tile, float4 (&r)[NP]) {
+    const long row = (long)tile * 32 + p;
+    const unsigned base = row < a.R ? (unsigned)(row * C + 4 * h) * 4u : OOB;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) r[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srd, base, (unsigned)(32 * g), 0));
+  };
+  const int stride = gridDim.x * NW;
+  int tile = blockIdx.x * NW + wave;
+  float4 xr[NP], gr[NP], xn[NP], gn[NP];
+  if (tile < a.ntiles) { load_rows(srdX, tile, xr); load_rows(srdD, tile, gr); }
+  for (; tile < a.ntiles; tile += stride) {
+    const bool more = tile + stride < a.ntiles;
+    if (more) { load_rows(srdX, tile + stride, xn); load_rows(srdD, tile + stride, gn); }
+    const long row = (long)tile * 32 + p;
+    const bool ok = row < a.R;
+    const float* mrow = a.mask1.kind == 1 ? a.mask1.mask + ((long)tile * 32 / a.mask1.rows_per_sample) * C : nullptr;
+    float hv[32];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int c0 = 8 * g + 4 * h;
+      const float4 sc = *reinterpret_cast<const float4*>(&tab[c0]), sh = *reinterpret_cast<const float4*>(&tab[C + c0]);
+      hv[4 * g + 0] = ok ? fmaxf(fmaf(xr[g].x, sc.x, sh.x), 0.f) : 0.f;
+      hv[4 * g + 1] = ok ? fmaxf(fmaf(xr[g].y, sc.y, sh.y), 0.f) : 0.f;
+      hv[4 * g + 2] = ok ? fmaxf(fmaf(xr[g].z, sc.z, sh.z), 0.f) : 0.f;
+      hv[4 * g + 3] = ok ? fmaxf(fmaf(xr[g].w, sc.w, sh.w), 0.f) : 0.f;
+      *reinterpret_cast<float4*>(pH + p * 256 + (((2 * g + h) ^ (p & 7)) << 4)) = make_float4(hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 w = *reinterpret_cast<const float4*>(smem + ((t * 8 + gq) * 64 + lane) * 16);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, hv[4 * gq + 0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, hv[4 * gq + 1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, hv[4 * gq + 2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, hv[4 * gq + 3], acc[t], 0, 0, 0);
+      }
+    }
+    float dcv[32];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int c0 = 8 * g + 4 * h, t = g >> 2, q = g & 3;
+      const float4 bb = *reinterpret_cast<const float4*>(&tab[2 * C + c0]);
+      float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (mrow) m4 = *reinterpret_cast<const float4*>(mrow + c0);
+      const float4 ga = *reinterpret_cast<const float4*>(&tab[3 * C + c0]), gb = *reinterpret_cast<const float4*>(&tab[4 * C + c0]);
+      const float4 gc = *reinterpret_cast<const float4*>(&tab[5 * C + c0]);
+      const float d0 = (acc[t][4 * q + 0] + bb.x) * m4.x, d1 = (acc[t][4 * q + 1] + bb.y) * m4.y;
+      const float d2 = (acc[t][4 * q + 2] + bb.z) * m4.z, d3 = (acc[t][4 * q + 3] + bb.w) * m4.w;
+      dcv[4 * g + 0] = ok ? m4.x * fmaf(gc.x, d0, fmaf(ga.x, gr[g].x, gb.x)) : 0.f;
+      dcv[4 * g + 1] = ok ? m4.y * fmaf(gc.y, d1, fmaf(ga.y, gr[g].y, gb.y)) : 0.f;
+      dcv[4 * g + 2] = ok ? m4.z * fmaf(gc.z, d2, fmaf(ga.z, gr[g].z, gb.z)) : 0.f;
+      dcv[4 * g + 3] = ok ? m4.w * fmaf(gc.w, d3, fmaf(ga.w, gr[g].w, gb.w)) : 0.f;
+      *reinterpret_cast<float4*>(pD + p * 256 + (((2 * g + h) ^ (p & 7)) << 4)) = make_float4(dcv[4 * g], dcv[4 * g + 1], dcv[4 * g + 2], dcv[4 * g + 3]);
+    }
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 w = *reinterpret_cast<const float4*>(smem + OFF_IMG2 + ((t * 8 + gq) * 64 + lane) * 16);
+        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, dcv[4 * gq + 0], acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, dcv[4 * gq + 1], acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, dcv[4 * gq + 2], acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, dcv[4 * gq + 3], acc2[t], 0, 0, 0);
+      }
+    }
+    // weight gradient (K = the tile's 32 pixels, 2 per MFMA): lane (channel, kh) reads pixel 2 v + kh of the two patches
+    {
+      asm volatile("" ::: "memory");
+      const int m = lane & 31, kh = lane >> 5;
+#pragma unroll 4
+      for (int v = 0; v < 16; ++v) {
+        const int pr = 2 * v + kh;
+        float av[NT], bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = 32 * t + m;
+          const int off = pr * 256 + ((((c >> 2) ^ (pr & 7)) << 4) | ((c & 3) << 2));
+          av[t] = *reinterpret_cast<const float*>(pH + off);
+          bv[t] = *reinterpret_cast<const float*>(pD + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], wacc[i][j], 0, 0, 0);
+      }
+      if (a.dbias) {
+        const int c = lane;
+        float sb = 0.f;
+#pragma unroll 8
+        for (int pp = 0; pp < 32; ++pp) sb += *reinterpret_cast<const float*>(pD + pp * 256 + ((((c >> 2) ^ (pp & 7)) << 4) | ((c & 3) << 2)));
+        Sb += (double)sb;
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int c0 = 8 * g + 4 * h, t = g >> 2, q = g & 3;
+      float4 o;
+      o.x = hv[4 * g + 0] > 0.f ? acc2[t][4 * q + 0] : 0.f; o.y = hv[4 * g + 1] > 0.f ? acc2[t][4 * q + 1] : 0.f;
+      o.z = hv[4 * g + 2] > 0.f ? acc2[t][4 * q + 2] : 0.f; o.w = hv[4 * g + 3] > 0.f ? acc2[t][4 * q + 3] : 0.f;
+      if (ok) *reinterpret_cast<float4*>(a.out + row * C + c0) = o;
+      *reinterpret_cast<float4*>(pD + p * 256 + (((2 * g + h) ^ (p & 7)) << 4)) = o;
+    }
+    {
+      const int c = lane;
+      float sg = 0.f, sgh = 0.f;
+#pragma unroll 8
+      for (int pp = 0; pp < 32; ++pp) {
+        const int off = pp * 256 + ((((c >> 2) ^ (pp & 7)) << 4) | ((c & 3) << 2));
+        const float g = *reinterpret_cast<const float*>(pD + off);
+        sg += g;
+        sgh = fmaf(g, *reinterpret_cast<const float*>(pH + off), sgh);
+      }
+      Sg += (double)sg;
+      Sgx += (double)sgh;      // sum dh1 * h1
+    }
+    if (more) {
+#pragma unroll
+      for (int g = 0; g < NP; ++g) { xr[g] = xn[g]; gr[g] = gn[g]; }
+    }
+  }
+  __syncthreads();
+  {
+    double* red = reinterpret_cast<double*>(smem + OFF_PATCH);
+    red[(wave * 3 + 0) * C + lane] = Sg;
+    red[(wave * 3 + 1) * C + lane] = Sgx;
+    red[(wave * 3 + 2) * C + lane] = Sb;
+    __syncthreads();
+    if (tid < C) {
+      double g = 0.0, gh = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { g += red[(w * 3 + 0) * C + tid]; gh += red[(w * 3 + 1) * C + tid]; b += red[(w * 3 + 2) * C + tid]; }
+      // sum dh1 * xhat1 with xhat1 = xh_a * h1 + xh_b on the support of dh1
+      atomic_add_f64(a.sums1 + tid, g);
+      atomic_add_f64(a.sums1 + C + tid, (double)tab[6 * C + tid] * gh + (double)tab[7 * C + tid] * g);
+      if (a.dbias) unsafeAtomicAdd(a.dbias + tid, (float)b);
+      if (blockIdx.x == 0 && a.dgamma2) { a.dgamma2[tid] = (float)a.sums2[C + tid]; a.dbeta2[tid] = (float)a.sums2[tid]; }
+    }
+    __syncthreads();
+  }
+  {
+    float* wred = reinterpret_cast<float*>(smem + OFF_PATCH);          // [4][C][C] floats = 64 KB (the patches: 64 KB)
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, co = 32 * j + l31;
+          wred[(wave * C + ci) * C + co] = wacc[i][j][r];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < C * C; idx += 256) {
+      const float s = wred[idx] + wred[C * C + idx] + wred[2 * C * C + idx] + wred[3 * C * C + idx];
+      unsafeAtomicAdd(a.dW + idx, s);
+    }
+  }
+}
+
 static int pw_check(const char* what, const void* x, const void* W, int64_t rows, int32_t C, const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2,
                     const mopoe_mask_ref* mask) {
   if (!x || !W || rows <= 0 || !bn1 || bn1->mode == 0 || bn1->C != C) { set_error("%s: bad arguments", what); return MOPOE_ERR_ARG; }
@@ -571,4 +931,61 @@ extern "C" int mopoe_block_front_bwd_bf16(const uint16_t* x, const uint16_t* dh2
   ProfScope prof((hipStream_t)stream, 6.0 * (double)rows * C * C, PROF_PW_FRONT + 2, (double)rows * C * 6.0);
   hipLaunchKernelGGL((pw_front_bwd_bf16_kernel<64>), dim3(pw_grid(a.ntiles, 1)), dim3(512), 0, (hipStream_t)stream, a);
   return check_launch("block_front_bwd_bf16");
+}
+
+static PwArgsF pw_args_f32(const float* x, const float* w1, const float* bias, int64_t rows, const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2,
+                           const mopoe_mask_ref* mask1) {
+  PwArgsF a = {};
+  a.x = x; a.W = w1; a.bias = bias; a.bn1 = *bn1; a.R = rows; a.ntiles = (int)((rows + 31) / 32);
+  a.x_bytes = (unsigned)((size_t)rows * 64 * 4);
+  if (bn2) a.bn2 = *bn2;
+  if (mask1) a.mask1 = *mask1;
+  return a;
+}
+static int pw_check_f32(const char* what, const void* x, const void* W, int64_t rows, int32_t C, const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2,
+                        const mopoe_mask_ref* mask) {
+  if (int rc = pw_check(what, x, W, rows, C, bn1, bn2, mask)) return rc;
+  if ((size_t)rows * C * 4 >= (1ull << 31)) { set_error("%s: tensors must be smaller than 2 GiB", what); return MOPOE_ERR_ARG; }
+  return 0;
+}
+static int pw_grid4(int ntiles, int per_cu) {
+  const int blocks = (ntiles + 3) / 4;
+  return blocks < 256 * per_cu ? blocks : 256 * per_cu;       // 4-wave blocks (the backward: one per CU, one wave per SIMD)
+}
+
+extern "C" int mopoe_block_front_stats(const float* x, const float* w1, const float* bias, int64_t rows, int32_t C,
+                                       const mopoe_bn_ref* bn1, const mopoe_mask_ref* mask1, double* stats_d1, void* stream) {
+  if (int rc = pw_check_f32("block_front_stats", x, w1, rows, C, bn1, nullptr, mask1)) return rc;
+  if (!stats_d1) { set_error("block_front_stats: null statistics"); return MOPOE_ERR_ARG; }
+  PwArgsF a = pw_args_f32(x, w1, bias, rows, bn1, nullptr, mask1);
+  a.stats_d1 = stats_d1;
+  ProfScope prof((hipStream_t)stream, 2.0 * (double)rows * C * C, PROF_PW_FRONT + 3, (double)rows * C * 4.0);
+  hipLaunchKernelGGL((pw_front_fwd_f32_kernel<false>), dim3(pw_grid4(a.ntiles, 2)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("block_front_stats");
+}
+
+extern "C" int mopoe_block_front_apply(const float* x, const float* w1, const float* bias, float* a2, int64_t rows, int32_t C,
+                                       const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, void* stream) {
+  if (int rc = pw_check_f32("block_front_apply", x, w1, rows, C, bn1, bn2, mask1)) return rc;
+  if (!a2 || !bn2 || ((uintptr_t)a2 & 15)) { set_error("block_front_apply: bad output / bn2"); return MOPOE_ERR_ARG; }
+  PwArgsF a = pw_args_f32(x, w1, bias, rows, bn1, bn2, mask1);
+  a.out = a2;
+  ProfScope prof((hipStream_t)stream, 2.0 * (double)rows * C * C, PROF_PW_FRONT + 4, (double)rows * C * 8.0);
+  hipLaunchKernelGGL((pw_front_fwd_f32_kernel<true>), dim3(pw_grid4(a.ntiles, 2)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("block_front_apply");
+}
+
+extern "C" int mopoe_block_front_bwd(const float* x, const float* dh2, const float* w1, const float* bias, float* dh1, int64_t rows, int32_t C,
+                                     const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, const double* sums2,
+                                     double* sums1, float* dw1, float* dbias, float* dgamma2, float* dbeta2, void* stream) {
+  if (int rc = pw_check_f32("block_front_bwd", x, w1, rows, C, bn1, bn2, mask1)) return rc;
+  if (!dh2 || !dh1 || !bn2 || bn2->mode != 1 || bn1->mode != 1 || !sums2 || !sums1 || !dw1 || ((uintptr_t)dh2 & 15) || ((uintptr_t)dh1 & 15)) {
+    set_error("block_front_bwd: bad arguments (bn1 and bn2 must carry batch statistics)"); return MOPOE_ERR_ARG;
+  }
+  PwArgsF a = pw_args_f32(x, w1, bias, rows, bn1, bn2, mask1);
+  a.dh2 = dh2; a.out = dh1; a.sums2 = sums2; a.sums1 = sums1; a.dW = dw1; a.dbias = dbias;
+  a.dgamma2 = dgamma2 && dbeta2 ? dgamma2 : nullptr; a.dbeta2 = dbeta2;
+  ProfScope prof((hipStream_t)stream, 6.0 * (double)rows * C * C, PROF_PW_FRONT + 5, (double)rows * C * 12.0);
+  hipLaunchKernelGGL(pw_front_bwd_f32_kernel, dim3(pw_grid4(a.ntiles, 1)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("block_front_bwd");
 }

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -711,18 +711,21 @@ def bn_relu_apply(x, bn: Bn):
 
 # ---- the front of a residual block as streaming kernels (csrc/pointwise.hip): bn1 -> relu -> conv1 (1x1) -> dropout -> bn2 -> relu
 BLOCK_FRONT = os.environ.get("MOPOE_BLOCK_FRONT", "1") != "0"     # A/B switch
+BLOCK_FRONT_F32 = os.environ.get("MOPOE_BLOCK_FRONT_F32", "1") != "0"     # A/B switch for the fp32 family alone
 
 
 def block_front_supported(x, g1: "Geom", mask1: Optional[Mask]) -> bool:
-    """bf16 family, 64 channels, a 1x1 conv, dropout absent or per (sample, channel) on whole 32-row tiles"""
-    return (BLOCK_FRONT and _is16(x) and g1.Cin == 64 and g1.Cout == 64 and g1.taps == 1 and _rows(x) % 32 == 0
+    """64 channels (either storage family), a 1x1 conv, dropout absent or per (sample, channel) on whole 32-row tiles"""
+    return (BLOCK_FRONT and x.dtype in (BF16, torch.float32) and (_is16(x) or BLOCK_FRONT_F32) and g1.Cin == 64 and g1.Cout == 64
+            and g1.taps == 1 and _rows(x) % 32 == 0
             and (mask1 is None or (mask1.kind == 1 and mask1.rows_per_sample % 32 == 0)))
 
 
 def block_front_stats(x, w1, bias, bn1: Bn, mask1: Optional[Mask], out_stats):
     """out_stats [2, C] += {sum, sumsq} of d1 = mask1 * (conv1(relu(bn1(x))) + bias), rounded to bf16; d1 itself is not written"""
     _dev(x, w1, bias, out_stats)
-    _check(lib().mopoe_block_front_stats_bf16(_p(x), _p(w1), _p(bias), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1), _mask(mask1),
+    fn = lib().mopoe_block_front_stats_bf16 if _is16(x) else lib().mopoe_block_front_stats
+    _check(fn(_p(x), _p(w1), _p(bias), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1), _mask(mask1),
                                               _p(out_stats), _stream()))
     return out_stats
 
@@ -731,7 +734,8 @@ def block_front_apply(x, w1, bias, bn1: Bn, bn2: Bn, mask1: Optional[Mask]):
     """a2 = relu(bn2(d1)) with d1 recomputed from x"""
     _dev(x, w1, bias)
     a2 = torch.empty_like(x)
-    _check(lib().mopoe_block_front_apply_bf16(_p(x), _p(w1), _p(bias), _p(a2), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1), _bn(bn2),
+    fn = lib().mopoe_block_front_apply_bf16 if _is16(x) else lib().mopoe_block_front_apply
+    _check(fn(_p(x), _p(w1), _p(bias), _p(a2), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1), _bn(bn2),
                                               _mask(mask1), _stream()))
     return a2
 
@@ -742,7 +746,8 @@ def block_front_bwd(x, dh2, w1, bias, bn1: Bn, bn2: Bn, mask1: Optional[Mask], s
     dbias [C] += (pre-zeroed accumulators); dgamma2 / dbeta2 [C] = bn2's affine gradients (= sums2[1] / sums2[0])"""
     _dev(x, dh2, w1, bias, sums2, sums1, dw1, dbias, dgamma2, dbeta2)
     dh1 = torch.empty_like(x)
-    _check(lib().mopoe_block_front_bwd_bf16(_p(x), _p(dh2), _p(w1), _p(bias), _p(dh1), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1),
+    fn = lib().mopoe_block_front_bwd_bf16 if _is16(x) else lib().mopoe_block_front_bwd
+    _check(fn(_p(x), _p(dh2), _p(w1), _p(bias), _p(dh1), C.c_int64(_rows(x)), x.shape[-1], _bn(bn1),
                                             _bn(bn2), _mask(mask1), _p(sums2), _p(sums1), _p(dw1), _p(dbias), _p(dgamma2), _p(dbeta2),
                                             _stream()))
     return dh1
@@ -1090,7 +1095,8 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 127
+    names = [None] * 130
+    names[127], names[128], names[129] = "pw_front_fwd_f32_kernel<false>", "pw_front_fwd_f32_kernel<true>", "pw_front_bwd_f32_kernel"
     names[124], names[125], names[126] = "pw_front_fwd_bf16_kernel<64, false>", "pw_front_fwd_bf16_kernel<64, true>", "pw_front_bwd_bf16_kernel<64>"
     names[122], names[123] = "wgrad_parity_bf16_kernel<64, *>", "wgrad_parity_bf16_kernel<128, *>"
     for m in (1, 2):

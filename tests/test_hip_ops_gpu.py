@@ -530,6 +530,59 @@ def test_token_softmax_grad(b, L, V, out_dtype):
         check("token_softmax_grad/bf16", got.float(), ref.to(torch.bfloat16).float(), rtol=1e-2, atol_rel=1e-4)
 
 
+@pytest.mark.parametrize("n,rps,drop", [(3, 64, True), (2, 1024, False), (5, 32, True), (1, 4096, True)])
+def test_block_front_streaming_kernels_f32(n, rps, drop):
+    """csrc/pointwise.hip, fp32 family: the front of a residual block (bn1 -> relu -> conv1 1x1 at 64 channels -> Dropout2d ->
+    bn2 -> relu) without ever writing d1 -- statistics pass, a2 pass, fused backward -- against the emulation and against the
+    HIP ops they replace (conv_fwd + bn_relu_apply / bn_bwd_apply + conv_dgrad + conv_wgrad)"""
+    c, rows = 64, n * rps
+    gen = torch.Generator().manual_seed(n * 1000 + rps)
+    x = torch.randn(n, rps, 1, c, generator=gen)
+    w1 = torch.randn(1, c, c, generator=gen) / 8
+    bias = 0.1 * torch.randn(c, generator=gen)
+    bn1 = make_bn(c, rows, 1, gen, x)
+    mask = Mask((torch.rand(n, c, generator=gen) < 0.5).float() * 2, 1, rps) if drop else None
+    g1 = Geom(n, rps, 1, rps, 1, c, c, 1, 1, 1, 1, 0, 0, False)
+    xd, wd, bd, bn1d, md = x.to(DEV), w1.to(DEV), bias.to(DEV), to_dev(bn1), to_dev(mask)
+    assert ops.block_front_supported(xd, g1, md)
+    st_ref, st = torch.zeros(2, c, dtype=torch.float64), torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    TB.block_front_stats(x, w1, bias, bn1, mask, st_ref)
+    ops.block_front_stats(xd, wd, bd, bn1d, md, st)
+    check("front32/stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
+    st_old = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    d1_old = ops.conv_fwd(xd, wd, g1, bn_in=bn1d, bias=bd, mask=md, out_stats=st_old)
+    check("front32/stats_vs_conv_fwd", st, st_old, rtol=1e-4, atol_rel=1e-4)
+    bn2 = Bn(torch.rand(c, generator=gen) + 0.5, 0.1 * torch.randn(c, generator=gen), 1, st_ref.clone(), rows)
+    bn2d = to_dev(bn2)
+    a2_ref = TB.block_front_apply(x, w1, bias, bn1, bn2, mask)
+    a2 = ops.block_front_apply(xd, wd, bd, bn1d, bn2d, md)
+    check("front32/a2", a2, a2_ref)
+    check("front32/a2_vs_bn_relu_apply", a2, ops.bn_relu_apply(d1_old, bn2d))
+    dh2 = torch.randn(rows, c, generator=gen).view(x.shape) * (a2_ref > 0)
+    mean2, rstd2, _, _ = TB.bn_coef(bn2)
+    d1_ref = TB._front_d1(x, w1, bias, bn1, mask)[1]
+    sums2 = torch.stack([dh2.reshape(rows, c).double().sum(0), (dh2 * ((d1_ref - mean2) * rstd2)).reshape(rows, c).double().sum(0)])
+    ref = dict(s1=torch.zeros(2, c, dtype=torch.float64), dw=torch.zeros(1, c, c), db=torch.zeros(c), dg=torch.zeros(c), dbt=torch.zeros(c))
+    dh1_ref = TB.block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask, sums2, ref["s1"], ref["dw"], ref["db"], ref["dg"], ref["dbt"])
+    s1 = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    dw, db, dg, dbt = (torch.zeros(1, c, c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV))
+    dh1 = ops.block_front_bwd(xd, dh2.to(DEV), wd, bd, bn1d, bn2d, md, sums2.to(DEV), s1, dw, db, dg, dbt)
+    check("front32/dh1", dh1, dh1_ref)
+    check("front32/sums1", s1, ref["s1"], rtol=5e-4, atol_rel=5e-4)
+    check("front32/dw1", dw, ref["dw"], rtol=5e-4, atol_rel=5e-4)
+    # (the column sums of a BatchNorm backward are analytically zero: the bound is fp32 rounding of an element times sqrt(rows))
+    noise = 2.0 ** -22 * float(dh2.abs().max()) * float((bn2.gamma * rstd2).abs().max()) * rows ** 0.5 * 8 + 1e-5
+    assert (db.cpu() - ref["db"]).abs().max().item() <= noise, ((db.cpu() - ref["db"]).abs().max().item(), noise)
+    check("front32/dgamma2", dg, ref["dg"], rtol=1e-6, atol_rel=1e-6)
+    check("front32/dbeta2", dbt, ref["dbt"], rtol=1e-6, atol_rel=1e-6)
+    dc1_old, _, _, _ = ops.bn_bwd_apply(dh2.to(DEV), d1_old, bn2d, sums2.to(DEV), mask=md, want_colsum=True)
+    s1_old = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+    dh1_old = ops.conv_dgrad(dc1_old, wd, g1, relu_bn=bn1d, xin=xd, bwd_sums=s1_old)
+    check("front32/dh1_vs_old_ops", dh1, dh1_old)
+    check("front32/sums1_vs_old_ops", s1, s1_old, rtol=5e-4, atol_rel=5e-4)
+    check("front32/dw1_vs_old_ops", dw, ops.conv_wgrad(xd, dc1_old, g1, bn_in=bn1d), rtol=5e-4, atol_rel=5e-4)
+
+
 @pytest.mark.parametrize("b,L,V", [(4, 128, 3520), (3, 7, 64), (2, 5, 8), (1, 3, 5000), (2, 4, 10240)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_vocabulary_head_from_logits(b, L, V, dtype):

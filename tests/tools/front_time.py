@@ -6,7 +6,9 @@ sys.path.insert(0, os.path.join(REPO, "mopoe-mimic_amd"))
 import torch
 from mimic_amd import ops
 from mimic_amd.ops import Bn, Geom, Mask
-dev, bf = "cuda", torch.bfloat16
+dev = "cuda"
+bf = torch.float32 if os.environ.get("DTYPE", "bf16") == "f32" else torch.bfloat16
+ES = 4 if bf == torch.float32 else 2
 
 
 def timed(fn, reps=20):
@@ -18,7 +20,7 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for n, hw in ((256, 64), (256, 32), (32, 128)):
+for n, hw in (((64, 64), (64, 32), (32, 128)) if bf == torch.float32 else ((256, 64), (256, 32), (32, 128))):
     c, rps = 64, hw * hw
     rows = n * rps
     x = torch.randn(n, hw, hw, c, device=dev).to(bf)
@@ -35,7 +37,7 @@ for n, hw in ((256, 64), (256, 32), (32, 128)):
     sums2 = torch.zeros(2, c, dtype=torch.float64, device=dev)
     s1 = torch.zeros(2, c, dtype=torch.float64, device=dev)
     dw, sm = torch.zeros(1, c, c, device=dev), torch.zeros(3, c, device=dev)
-    unit = rows * c * 2 / 1e6   # MB per pass
+    unit = rows * c * ES / 1e6   # MB per pass
     t = [timed(lambda: ops.block_front_stats(x, w1, None, bn1, mask, st)),
          timed(lambda: ops.block_front_apply(x, w1, None, bn1, bn2, mask)),
          timed(lambda: ops.block_front_bwd(x, dh2, w1, None, bn1, bn2, mask, sums2, s1, dw, None, sm[0], sm[1]))]

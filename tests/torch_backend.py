@@ -214,7 +214,7 @@ def _front_d1(x, w1, bias, bn1, mask1):
     mm = _mask_mult(d, mask1)
     if mm is not None:
         d = d * mm
-    return h1, _q16(d)
+    return h1, (_q16(d) if x.dtype == BF16 else d)
 
 
 def block_front_stats(x, w1, bias, bn1, mask1, out_stats):
@@ -226,7 +226,7 @@ def block_front_stats(x, w1, bias, bn1, mask1, out_stats):
 def block_front_apply(x, w1, bias, bn1, bn2, mask1):
     _, d1 = _front_d1(x, w1, bias, bn1, mask1)
     _, _, scale, shift = bn_coef(bn2)
-    return _q16(torch.relu(d1 * scale + shift)).to(x.dtype)
+    return _store(torch.relu(d1 * scale + shift), x.dtype)[1]
 
 
 def block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask1, sums2, sums1, dw1, dbias=None, dgamma2=None, dbeta2=None):
@@ -236,9 +236,9 @@ def block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask1, sums2, sums1, dw1, dbias=
     mm = _mask_mult(dc1, mask1)
     if mm is not None:
         dc1 = dc1 * mm
-    dc1 = _q16(dc1)
+    dc1 = _q16(dc1) if x.dtype == BF16 else dc1
     dh1 = (dc1.reshape(-1, c) @ _f(w1).reshape(c, c).t()).view(x.shape) * (h1 > 0).to(dc1.dtype)
-    dh1 = _q16(dh1)
+    dh1 = _q16(dh1) if x.dtype == BF16 else dh1
     mean1, rstd1, _, _ = bn_coef(bn1)
     xhat1 = (_f(x) - mean1) * rstd1
     sums1[0] += dh1.reshape(-1, c).double().sum(0)
@@ -253,7 +253,7 @@ def block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask1, sums2, sums1, dw1, dbias=
 
 
 def block_front_supported(x, g1, mask1):
-    return (real_ops.BLOCK_FRONT and x.dtype == BF16 and g1.Cin == 64 and g1.Cout == 64 and g1.taps == 1
+    return (real_ops.BLOCK_FRONT and x.dtype in (BF16, torch.float32) and g1.Cin == 64 and g1.Cout == 64 and g1.taps == 1
             and (x.numel() // x.shape[-1]) % 32 == 0 and (mask1 is None or (mask1.kind == 1 and mask1.rows_per_sample % 32 == 0)))
 
 
