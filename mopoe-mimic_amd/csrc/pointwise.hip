@@ -243,7 +243,8 @@ __global__ __launch_bounds__(512, 2) void pw_front_bwd_bf16_kernel(const PwArgs 
     tab[2 * C + c] = a.bias ? a.bias[c] : 0.f;
     // dc1 = mask * ga * (dh2 - c1 - xhat2 * c2), xhat2 = (d1 - mean2) * rstd2, c1 = sum dh2 / n, c2 = sum dh2 xhat2 / n
     //     = mask * (ga * dh2 + gb + gc * d1)
-    const double c1 = a.sums2[c] * a.bn2.inv_count, c2 = a.sums2[C + c] * a.bn2.inv_count;
+    // (running statistics -- a backward in eval mode -- : bn2 is a fixed affine map, no batch terms)
+    const double c1 = a.bn2.mode == 1 ? a.sums2[c] * a.bn2.inv_count : 0.0, c2 = a.bn2.mode == 1 ? a.sums2[C + c] * a.bn2.inv_count : 0.0;
     const float ga = k2.scale;                                   // gamma2 * rstd2
     tab[3 * C + c] = ga;
     tab[4 * C + c] = (float)(-(double)ga * c1 + (double)ga * c2 * (double)k2.rstd * (double)k2.mean);
@@ -665,7 +666,8 @@ __global__ __launch_bounds__(256, 1) void pw_front_bwd_f32_kernel(const PwArgsF 
     const BnC k2 = bn_coef(a.bn2, c);
     tab[c] = k1.scale; tab[C + c] = k1.shift;
     tab[2 * C + c] = a.bias ? a.bias[c] : 0.f;
-    const double c1 = a.sums2[c] * a.bn2.inv_count, c2 = a.sums2[C + c] * a.bn2.inv_count;
+    // (running statistics -- a backward in eval mode -- : bn2 is a fixed affine map, no batch terms)
+    const double c1 = a.bn2.mode == 1 ? a.sums2[c] * a.bn2.inv_count : 0.0, c2 = a.bn2.mode == 1 ? a.sums2[C + c] * a.bn2.inv_count : 0.0;
     const float ga = k2.scale;
     tab[3 * C + c] = ga;
     tab[4 * C + c] = (float)(-(double)ga * c1 + (double)ga * c2 * (double)k2.rstd * (double)k2.mean);
@@ -920,8 +922,8 @@ extern "C" int mopoe_block_front_bwd_bf16(const uint16_t* x, const uint16_t* dh2
                                           const mopoe_mask_ref* mask1, const double* sums2, double* sums1, float* dw1, float* dbias,
                                           float* dgamma2, float* dbeta2, void* stream) {
   if (int rc = pw_check("block_front_bwd_bf16", x, w1, rows, C, bn1, bn2, mask1)) return rc;
-  if (!dh2 || !dh1 || !bn2 || bn2->mode != 1 || !sums2 || !sums1 || !dw1 || ((uintptr_t)dh2 & 15) || ((uintptr_t)dh1 & 15)) {
-    set_error("block_front_bwd_bf16: bad arguments (bn2 must carry batch statistics)"); return MOPOE_ERR_ARG;
+  if (!dh2 || !dh1 || !bn2 || !sums2 || !sums1 || !dw1 || ((uintptr_t)dh2 & 15) || ((uintptr_t)dh1 & 15)) {
+    set_error("block_front_bwd_bf16: bad arguments"); return MOPOE_ERR_ARG;
   }
   PwArgs a = {};
   a.x = x; a.dh2 = dh2; a.W = w1; a.bias = bias; a.out = dh1; a.bn1 = *bn1; a.bn2 = *bn2; a.sums2 = sums2; a.sums1 = sums1;
@@ -979,8 +981,8 @@ extern "C" int mopoe_block_front_bwd(const float* x, const float* dh2, const flo
                                      const mopoe_bn_ref* bn1, const mopoe_bn_ref* bn2, const mopoe_mask_ref* mask1, const double* sums2,
                                      double* sums1, float* dw1, float* dbias, float* dgamma2, float* dbeta2, void* stream) {
   if (int rc = pw_check_f32("block_front_bwd", x, w1, rows, C, bn1, bn2, mask1)) return rc;
-  if (!dh2 || !dh1 || !bn2 || bn2->mode != 1 || bn1->mode != 1 || !sums2 || !sums1 || !dw1 || ((uintptr_t)dh2 & 15) || ((uintptr_t)dh1 & 15)) {
-    set_error("block_front_bwd: bad arguments (bn1 and bn2 must carry batch statistics)"); return MOPOE_ERR_ARG;
+  if (!dh2 || !dh1 || !bn2 || !sums2 || !sums1 || !dw1 || ((uintptr_t)dh2 & 15) || ((uintptr_t)dh1 & 15)) {
+    set_error("block_front_bwd: bad arguments"); return MOPOE_ERR_ARG;
   }
   PwArgsF a = pw_args_f32(x, w1, bias, rows, bn1, bn2, mask1);
   a.dh2 = dh2; a.out = dh1; a.sums2 = sums2; a.sums1 = sums1; a.dW = dw1; a.dbias = dbias;

@@ -712,10 +712,17 @@ def bn_relu_apply(x, bn: Bn):
 # ---- the front of a residual block as streaming kernels (csrc/pointwise.hip): bn1 -> relu -> conv1 (1x1) -> dropout -> bn2 -> relu
 BLOCK_FRONT = os.environ.get("MOPOE_BLOCK_FRONT", "1") != "0"     # A/B switch
 BLOCK_FRONT_F32 = os.environ.get("MOPOE_BLOCK_FRONT_F32", "1") != "0"     # A/B switch for the fp32 family alone
+# fp32: the two forward passes each pay conv1's 64 MFMAs per 32 pixels at the fp32 rate (one MFMA = 64 cycles for 2 k) and come
+# out slower than conv_fwd + bn_relu_apply (rb1 at config #2: 101.9 against 91.7 us); the fused backward wins (100.0 against
+# 129.9 us).  So the fp32 family keeps the forward of round 3 (d1 written) and takes only the backward kernel.
+BLOCK_FRONT_F32_FWD = os.environ.get("MOPOE_BLOCK_FRONT_F32_FWD", "0") != "0"
 
 
-def block_front_supported(x, g1: "Geom", mask1: Optional[Mask]) -> bool:
-    """64 channels (either storage family), a 1x1 conv, dropout absent or per (sample, channel) on whole 32-row tiles"""
+def block_front_supported(x, g1: "Geom", mask1: Optional[Mask], forward: bool = False) -> bool:
+    """64 channels (either storage family), a 1x1 conv, dropout absent or per (sample, channel) on whole 32-row tiles.
+    forward=True: is the FORWARD pair (statistics + apply passes, d1 never written) to be used as well?"""
+    if forward and not _is16(x) and not BLOCK_FRONT_F32_FWD:
+        return False
     return (BLOCK_FRONT and x.dtype in (BF16, torch.float32) and (_is16(x) or BLOCK_FRONT_F32) and g1.Cin == 64 and g1.Cout == 64
             and g1.taps == 1 and _rows(x) % 32 == 0
             and (mask1 is None or (mask1.kind == 1 and mask1.rows_per_sample % 32 == 0)))

@@ -200,7 +200,8 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         s = lane.run(lambda: ops.conv_fwd(x, wsel(sconv), g2, bias=sconv.bias, out_stats=st_s), x)
         # the block's front as streaming kernels (csrc/pointwise.hip) where they exist: d1 is never written -- one pass over x for
         # its statistics (train), one that recomputes it and writes a2 = relu(bn2(d1)); the backward recomputes it once more
-        front = _materialize(g2, x) and ops.block_front_supported(x, g1, mask1)
+        front_bwd = _materialize(g2, x) and ops.block_front_supported(x, g1, mask1)
+        front = _materialize(g2, x) and ops.block_front_supported(x, g1, mask1, forward=True)
         if front:
             if training:
                 ops.block_front_stats(x, wsel(p.conv1), p.conv1.bias, bn1, mask1, st_d1)
@@ -230,7 +231,8 @@ def trunk_forward(blocks: List[BlockSpec], x, x_stats, training: bool, dropout: 
         else:
             m = ops.conv_fwd(op2, wsel(p.conv2), g2, bn_in=bn_in2, bias=p.conv2.bias, mask=mask2)
             out = ops.block_out_fwd(s, m, bns, out_stats=st_out)
-        saved.append(dict(x=x, d1=d1, a2=a2, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2))
+        saved.append(dict(x=x, d1=d1, a2=a2, s=s, bn1=bn1, bn2=bn2, bns=bns, mask1=mask1, mask2=mask2, g1=g1, g2=g2,
+                          front_bwd=front_bwd or front))
         x, x_stats = out, st_out
     return x, saved, running
 
@@ -301,8 +303,8 @@ def trunk_backward(blocks: List[BlockSpec], saved, g, grads: Dict[str, torch.Ten
                                                        small=take_f(4, g2.Cout))
         sums2 = take_d(g1.Cout)
         a2 = sv.get("a2")
-        front = d1 is None      # (the forward ran the streaming front: d1 was never written)
-        if front:
+        front = bool(sv.get("front_bwd"))      # the fused backward of the block's front (csrc/pointwise.hip)
+        if d1 is None:      # (the forward ran the streaming front too: d1 was never written)
             # conv2's input gradient reads its ReLU mask and x-hat off a2 = relu(bn2(d1)) (mopoe_bn_ref mode 3)
             bn2y = Bn(bn2.gamma, bn2.beta, 3, sums=bn2.sums, count=bn2.count, eps=bn2.eps)
             dh2 = ops.conv_dgrad(dm, wsel(p.conv2), g2, relu_bn=bn2y, xin=a2, bwd_sums=sums2)

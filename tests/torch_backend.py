@@ -252,7 +252,9 @@ def block_front_bwd(x, dh2, w1, bias, bn1, bn2, mask1, sums2, sums1, dw1, dbias=
     return dh1.to(x.dtype)
 
 
-def block_front_supported(x, g1, mask1):
+def block_front_supported(x, g1, mask1, forward=False):
+    if forward and x.dtype != BF16 and not real_ops.BLOCK_FRONT_F32_FWD:
+        return False
     return (real_ops.BLOCK_FRONT and x.dtype in (BF16, torch.float32) and g1.Cin == 64 and g1.Cout == 64 and g1.taps == 1
             and (x.numel() // x.shape[-1]) % 32 == 0 and (mask1 is None or (mask1.kind == 1 and mask1.rows_per_sample % 32 == 0)))
 
