@@ -77,6 +77,8 @@ FUSE_MIX = os.environ.get("MOPOE_FUSE_MIX", "1") != "0"   # residual mix in conv
 FUSE_NEXT_REDUCE = os.environ.get("MOPOE_FUSE_NEXT_REDUCE", "1") != "0"
 LANES = os.environ.get("MOPOE_LANES", "0,1").split(",")   # 0 = weight gradients, 1 = projection-shortcut branch
 LANES_IN_CAPTURE = os.environ.get("MOPOE_LANES_IN_CAPTURE", "0") != "0"   # (tests/tools/capture_probe_torch.py)
+# lanes (by number) the IN-LINE network may use inside a capture, e.g. "0" = its weight gradients; "" = none
+INLINE_LANES_IN_CAPTURE = [x for x in os.environ.get("MOPOE_INLINE_LANES_IN_CAPTURE", "").split(",") if x]
 _side_streams = {}
 
 
@@ -103,6 +105,13 @@ class _WgradLane:
         # The graph therefore keeps a star topology: modality streams forked from the capture stream, nothing nested.
         self.enabled = (WGRAD_SIDE_STREAM and device.type == "cuda" and str(which) in LANES
                         and (LANES_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
+        if (not self.enabled and INLINE_LANES_IN_CAPTURE and WGRAD_SIDE_STREAM and device.type == "cuda"
+                and str(which) in INLINE_LANES_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
+            # the network that runs IN LINE on the capture's origin stream (the text network): its lane is a one-level fork,
+            # which the bundled HIP runtime accepts (a fork under a modality fork is what crashes capture_end)
+            from .lanes import _net_streams
+            cur = torch.cuda.current_stream(device)
+            self.enabled = all(cur.cuda_stream != s.cuda_stream for s in _net_streams.values())
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
             self.side = _side_stream(device, which, self.main)
