@@ -28,7 +28,6 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -116,15 +115,18 @@ def launch_ranks(n):
     made any GPU call (it never makes one: importing torch and parsing flags do not initialise HIP), as the reference's
     Main does with mp.spawn (mimic/main_mimic.py:44-48,65-69).  A process that has initialised the GPU is never re-exec'd.
     Rank 0 prints the JSON line on the inherited stdout; the exit code is the worst of the ranks'."""
-    port = os.environ.get("MASTER_PORT")
-    if port is None:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = str(s.getsockname()[1])
+    # rendezvous through a file in a fresh temporary directory (a TCP port picked here could be taken by another process before
+    # the ranks bind it; a collision shows up as a rendezvous that hangs until the driver's limit).  MASTER_PORT, if the caller
+    # set one, still wins: torch.distributed.run-style launches are unchanged.
+    import tempfile
+    rdzv_dir = tempfile.mkdtemp(prefix="mopoe_rdzv_")
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        if "MASTER_PORT" in os.environ:
+            env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        else:
+            env["MOPOE_RDZV_FILE"] = os.path.join(rdzv_dir, "rdzv")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -144,6 +146,8 @@ def launch_ranks(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        import shutil
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
     return rc
 
 
@@ -178,10 +182,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("MOPOE_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; gloo only for rehearsal
+        rdzv = os.environ.get("MOPOE_RDZV_FILE")                  # (set by launch_ranks: file rendezvous, no TCP port)
+        kw = dict(init_method=f"file://{rdzv}") if rdzv else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from mimic_amd import ops, run_epochs as RE
     from mimic_amd.parallel import GradAllReducer

@@ -24,11 +24,11 @@ def _worker(rank, port, outdir):
     for p in PATHS:
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    # (file rendezvous inside the test's temporary directory: no TCP port to collide on between concurrent or back-to-back runs)
+    dist.init_process_group("nccl", init_method=f"file://{os.path.join(outdir, 'rdzv')}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     import mopoe_ref as R
     from model_util import build_exp
     from mimic_amd import run_epochs as RE
@@ -71,9 +71,8 @@ def _worker(rank, port, outdir):
 
 
 def test_three_graph_step_over_rccl_matches_eager():
-    port = 29700 + (os.getpid() % 200)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(port, d), nprocs=1, join=True)
+        mp.spawn(_worker, args=(0, d), nprocs=1, join=True)
         res = torch.load(os.path.join(d, "out.pt"))
     ref = res["plain"]["losses"]
     for kind in ("eager_dp", "graph_dp"):
@@ -100,7 +99,7 @@ def test_bench_starts_its_own_ranks():
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "3",
                           "--warmup", "1", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True,
-                         timeout=900, cwd=REPO, env=env)
+                         timeout=300, cwd=REPO, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
