@@ -47,6 +47,8 @@ CASES = {
     "c2_b64": (C2, 64, 41, "train_nodrop", "fp32", "ref32"),
     "c2_dimg128_b4": (dict(C2, DIM_img=128), 4, 43, "train_nodrop", "fp32", "ref64"),
     "c5_b4": (C5, 4, 31, "train_nodrop", "fp32", "ref64"),
+    "c5_b32": (C5, 32, 33, "train_nodrop", "fp32", "ref32"),                          # config #5's shape at its full per-GPU batch, fp32
+    "c2_dimg128_b64": (dict(C2, DIM_img=128), 64, 45, "train_nodrop", "fp32", "ref32"),   # SURVEY 8d's secondary point at full batch
     "c3_b256_bf16": (C2, 256, 91, "train_nodrop", "bf16", "ref32"),
     "c5_b32_bf16": (C5, 32, 95, "train_nodrop", "bf16", "ref32"),
     # a small configuration the bf16 family accepts (every GEMM K a multiple of 32): BatchNorm batch statistics, dropout (the

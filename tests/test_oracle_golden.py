@@ -258,7 +258,7 @@ def test_g7_oracle_against_the_reference_at_config_2_shape():
         worst = max(worst, rel)
         # the oracle (fp32) against the reference's fp64 gradient: as close as the reference's own fp32 run (cpu_l2), x3
         assert rel <= max(2e-3, 3 * cpu_l2), (name, rel, cpu_l2)
-    for case in ("c2_b64", "c2_dimg128_b4", "c5_b4", "c3_b256_bf16", "c5_b32_bf16"):
+    for case in ("c2_b64", "c2_dimg128_b4", "c2_dimg128_b64", "c5_b4", "c5_b32", "c3_b256_bf16", "c5_b32_bf16"):
         dev_loss, dev_grad = load(f"g7_{case}")["oracle_vs_reference"]
         assert dev_loss <= 1e-6 and dev_grad <= 1e-2, (case, dev_loss, dev_grad)
     tr = load("g7_traj_c3_b16")
