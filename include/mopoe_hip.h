@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 17
+#define MOPOE_ABI_VERSION 18
 
 /* error codes */
 #define MOPOE_OK 0
@@ -107,10 +107,15 @@ size_t mopoe_conv_workspace_bytes(void);
  *            MFMA registers; channel counts multiples of 8)
  *          | 12..15 = 128x128, 128x64, 64x64, 256x128 on LDS-DMA (csrc/conv_gemm_glds.inc: buffer_load ... lds, 32-deep stages,
  *            2-4 LDS buffers; K channels % 32 == 0, channel counts % 4 == 0; with BN -> ReLU on load: 12, 14, 15 only)
+ *          | 16..19 = tiles 12..15 with the fp32 products computed on the bf16 matrix pipe: each fp32 operand value is split
+ *            EXACTLY into three bf16 parts in registers (a = h + m + l) and six of the nine partial products (all but m l, l m, l l,
+ *            each below 2^-24 |a b|) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- results within fp32 rounding of the
+ *            fp32-MFMA tiles', measured closer to fp64 than theirs; plain operand forms only (no BN -> ReLU on load); 19 has 3 buffers
  *   split  0 auto | n >= 1 blocks sharing one tile's tap x channel reduction, finished by the last-arriving block (needs workspace)
  * fp32 weight gradient (mopoe_conv_wgrad):
  *   tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap, register-staged, 16 pixels per chunk)
  *          | 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per stage; channel counts % 4 == 0; 5 needs > 64 channels on both sides)
+ *          | 7, 8 = tiles 5, 6 with the fp32 products on the bf16 matrix pipe (as tiles 16..19 above; plain operand only)
  *   split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp)
  * bf16 family (mopoe_conv_fwd_bf16 / _fwd_mix_bf16 / _dgrad_bf16):
  *   tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 (register-staged, 32-deep K chunk)
@@ -454,8 +459,10 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   120..121 wgrad_gemm_bf16_glds_kernel, two taps per block (tile 7): gathered side = activations / gradient rows
  *   122..123 wgrad_parity_bf16_kernel (tiles 8 / 9: four taps per block), S tile 64 / 128
  *   124..126 pw_front_fwd_bf16_kernel<64, false> (statistics pass), <64, true> (a2 pass), pw_front_bwd_bf16_kernel<64>
- *   127..129 pw_front_fwd_f32_kernel<false>, <true>, pw_front_bwd_f32_kernel */
-#define MOPOE_PROF_KINDS 130
+ *   127..129 pw_front_fwd_f32_kernel<false>, <true>, pw_front_bwd_f32_kernel
+ *   130..137 gather_gemm_f32_glds_kernel<..., EMU = 1> (fp32 tiles 16..19): (tile - 16) * 2 + (input gradient ? 1 : 0)
+ *   138..139 wgrad_gemm_f32_glds_kernel<..., EMU = 1> (fp32 wgrad tiles 7, 8) */
+#define MOPOE_PROF_KINDS 140
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

@@ -1144,6 +1144,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   // Wide outputs always take the 128x128 tile (best operand reuse); when that leaves the chip under-filled the
   // tap x channel reduction is split across blocks instead of shrinking the tile.
   int cfg;
+  bool emu = false;
   if (Cn > 64) cfg = (a.rows_per_phase > 64 || Cn >= 256) ? 0 : 2;
   else cfg = a.rows_per_phase >= 256L * 64 ? 1 : 2;
 #ifdef TILE_N64_REMAINDER
@@ -1151,8 +1152,14 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
   if (cfg == 0 && (Cn % 128) == 64 && a.rows_per_phase >= 256L * TILE_N64_REMAINDER) cfg = 1;
 #endif
   if (plan && plan->tile >= 0) {
-    if (plan->tile > 15) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..15)", plan->tile); return MOPOE_ERR_ARG; }
+    if (plan->tile > 19) { set_error("conv plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: 0..19)", plan->tile); return MOPOE_ERR_ARG; }
     cfg = plan->tile;
+    // 16..19 = tiles 12..15 with the fp32 products on the bf16 matrix pipe (conv_gemm_glds.inc, EMU); not with BN on load
+    if (cfg >= 16) {
+      if (a.bn_in.mode != 0) { set_error("conv plan: tile %d (split-bf16 products) has no BN-on-load form", cfg); return MOPOE_ERR_ARG; }
+      emu = true;
+      cfg -= 4;
+    }
     // 12..15 = LDS-DMA family (conv_gemm_glds.inc): vector path, K channels a multiple of 32; with BN on load the tiles with
     // two or four buffers (12, 14, 15).  A plan that asks for one where it does not apply is refused (the tuner never offers it).
     if (cfg >= 12 && (!vec || Ck % 32 != 0 || (a.bn_in.mode != 0 && cfg == 13))) {
@@ -1204,7 +1211,8 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     const int spec = (vec && Ck % gbk == 0) ? (w_nk ? 3 : (a.bn_in.mode != 0 ? 2 : 1)) : 0;
     // algorithmic bytes: one read of the gathered activation + one write of the result
     const double abytes = ((double)g->N * a.Hx * a.Wx * Ck + (double)a.rows_total * Cn) * sizeof(float);
-    ProfScope prof(stream, flops, cfg >= 12 ? PROF_F32_GLDS + (cfg - 12) * 3 + (spec - 1)
+    ProfScope prof(stream, flops, emu ? PROF_F32_GLDS_EMU + (cfg - 12) * 2 + (spec == 3 ? 1 : 0)
+                                      : cfg >= 12 ? PROF_F32_GLDS + (cfg - 12) * 3 + (spec - 1)
                                             : (cfg >= 8 ? PROF_DIRECT + (cfg - 8) * 4 + spec
                                                         : (vec ? PROF_GATHER_VEC + cfg * 4 + spec : PROF_GATHER_SCALAR + cfg)), abytes);
     dim3 grid((unsigned)gx, nNt, nphase * a.nsplit);
@@ -1228,7 +1236,21 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     if (spec == 1) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
     else hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
   } while (0)
-    if (cfg >= 12) {
+#define MOPOE_LAUNCH_GLDS_EMU(BM_, BN_, WM_, WN_, ST_)                                                                                   \
+  do {                                                                                                                                \
+    if (spec == 1) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 1, ST_, 1>), grid, dim3(64 * WM_ * WN_), 0, stream, a); \
+    else hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<BM_, BN_, WM_, WN_, 3, ST_, 1>), grid, dim3(64 * WM_ * WN_), 0, stream, a);          \
+  } while (0)
+    if (emu) {
+      // (the two wide tiles: one 4-wave block per CU -- 512 registers per wave for the software pipeline -- and the LDS that frees
+      // spent on stages: 4 x 32 KB, 3 x 48 KB)
+      if (cfg == 12) MOPOE_LAUNCH_GLDS_EMU(128, 128, 2, 2, 2);
+      else if (cfg == 13) MOPOE_LAUNCH_GLDS_EMU(128, 64, 2, 2, 3);
+      else if (cfg == 14) MOPOE_LAUNCH_GLDS_EMU(64, 64, 2, 2, 4);
+      else MOPOE_LAUNCH_GLDS_EMU(256, 128, 4, 2, 3);
+    }
+#undef MOPOE_LAUNCH_GLDS_EMU
+    else if (cfg >= 12) {
       if (spec == 2) {
         if (cfg == 12) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<128, 128, 2, 2, 2, 2>), grid, dim3(256), 0, stream, a);
         else if (cfg == 14) hipLaunchKernelGGL((gather_gemm_f32_glds_kernel<64, 64, 2, 2, 2, 4>), grid, dim3(256), 0, stream, a);
@@ -1349,12 +1371,15 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   bool big = g->Cin > 64 && g->Cout > 64;
   // plan tiles: 0 = 128x128, 2 = 64x64 (register-staged, 16 pixels per chunk); 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per
   // stage: conv_gemm_glds.inc; vector path only)
-  if (plan && (plan->tile == 2 || plan->tile == 6)) big = false;   // the plan may ask for 64x64 tiles on wide layers too
-  else if (plan && plan->tile == 5) {
+  // 7, 8 = tiles 5, 6 with the fp32 products on the bf16 matrix pipe (EMU; plain operand only)
+  const bool wemu = plan && (plan->tile == 7 || plan->tile == 8);
+  if (wemu && a.bn_in.mode != 0) { set_error("wgrad plan: tile %d (split-bf16 products) has no BN-on-load form", plan->tile); return MOPOE_ERR_ARG; }
+  if (plan && (plan->tile == 2 || plan->tile == 6 || plan->tile == 8)) big = false;   // the plan may ask for 64x64 tiles on wide layers too
+  else if (plan && (plan->tile == 5 || plan->tile == 7)) {
     // (mirrors the tuner, mimic_amd/ops.py: _wgrad_candidates -- the 128 tile is never offered with <= 64 channels on a side)
-    if (!big) { set_error("wgrad plan: tile 5 (128x128 on LDS-DMA) needs more than 64 channels on both sides (%d, %d)", g->Cin, g->Cout); return MOPOE_ERR_ARG; }
+    if (!big) { set_error("wgrad plan: tile %d (128x128 on LDS-DMA) needs more than 64 channels on both sides (%d, %d)", plan->tile, g->Cin, g->Cout); return MOPOE_ERR_ARG; }
   }
-  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6)", plan->tile); return MOPOE_ERR_ARG; }
+  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6, 7, 8)", plan->tile); return MOPOE_ERR_ARG; }
   const bool glds = plan && plan->tile >= 5;
   if (glds && !vec) { set_error("wgrad plan: the LDS-DMA tiles need the vector path (channel counts %% 4 == 0, aligned tensors)"); return MOPOE_ERR_ARG; }
   const int T = big ? 128 : 64;
@@ -1383,10 +1408,14 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   const int spec = a.fast ? (a.bn_in.mode != 0 ? 2 : 1) : 0;
   const double abytes = ((double)g->N * g->Hs * g->Ws * (g->transposed ? g->Cin : g->Cout)
                          + (double)g->N * g->Hb * g->Wb * (g->transposed ? g->Cout : g->Cin)) * sizeof(float);   // both operands, once
-  ProfScope prof(stream, flops, glds ? PROF_F32_WGRAD_GLDS + (big ? 0 : 2) + (a.bn_in.mode != 0 ? 1 : 0)
+  ProfScope prof(stream, flops, wemu ? PROF_F32_WGRAD_GLDS_EMU + (big ? 0 : 1)
+                                : glds ? PROF_F32_WGRAD_GLDS + (big ? 0 : 2) + (a.bn_in.mode != 0 ? 1 : 0)
                                      : (vec ? PROF_WGRAD_VEC + (big ? 0 : 3) + spec : PROF_WGRAD_SCALAR + (big ? 0 : 1)), abytes);
   dim3 grid(nI * nJ, taps, (unsigned)split);
-  if (glds) {
+  if (wemu) {
+    if (big) hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<128, false, 2, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<64, false, 4, 1>), grid, dim3(256), 0, stream, a);
+  } else if (glds) {
     const bool xf = a.bn_in.mode != 0;
     if (big) {
       if (xf) hipLaunchKernelGGL((wgrad_gemm_f32_glds_kernel<128, true, 2>), grid, dim3(256), 0, stream, a);

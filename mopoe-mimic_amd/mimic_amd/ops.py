@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -256,8 +256,13 @@ _conv_calls = 0
 _plans = {}
 _GATHER_TILES = ((128, 128), (256, 64), (64, 64), (256, 128), (128, 64), (64, 64), (128, 64), (128, 128),
                  (128, 128), (256, 64), (64, 64), (128, 64),   # 8..11: the LDS-free kernel
-                 (128, 128), (128, 64), (64, 64), (256, 128))  # 12..15: the LDS-DMA family (csrc/conv_gemm_glds.inc)
+                 (128, 128), (128, 64), (64, 64), (256, 128),  # 12..15: the LDS-DMA family (csrc/conv_gemm_glds.inc)
+                 (128, 128), (128, 64), (64, 64), (256, 128))  # 16..19: the same with the fp32 products on the bf16 matrix pipe
 F32_GLDS = os.environ.get("MOPOE_F32_GLDS", "1") != "0"       # A/B switch: keep the tuner off the LDS-DMA tiles
+# A/B switch: tiles 16..19 (plain operand) offered.  The products are the same fp32 numbers -- each operand is split exactly
+# into three bf16 parts and six of the nine partial products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the error
+# against fp64 is lower than that of v_mfma_f32_32x32x2_f32 (csrc/conv_gemm_glds.inc, tests: test_f32_products_on_the_bf16_pipe)
+F32_SPLIT_BF16 = os.environ.get("MOPOE_F32_SPLIT_BF16", "1") != "0"
 _SPLITS = (2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128)
 
 
@@ -376,7 +381,9 @@ def _gather_candidates(kind: str, g: Geom, ws_bytes: int, plain_operand: bool = 
             continue   # LDS-free kernel: 8-deep K steps
         if tile >= 12 and not (F32_GLDS and ck % 32 == 0 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and (plain_operand or tile != 13)):
             continue   # LDS-DMA family: 32-deep stages, vector path (with BN on load: the tiles with 2 or 4 buffers)
-        cap = (256 if tile == 15 else 512) if tile >= 12 else (512 if tile in (0, 1, 3) else 768)   # blocks resident at once
+        if tile >= 16 and not (F32_SPLIT_BF16 and plain_operand):
+            continue   # products on the bf16 pipe: plain operand forms
+        cap = (256 if tile in (15, 19) else 512) if tile >= 12 else (512 if tile in (0, 1, 3) else 768)   # blocks resident at once
         cands[(tile, 1)] = min(1.0, blocks / cap)
         for s in _SPLITS:
             if s * 2 <= iters and blocks * s <= 2048 and s * per <= ws_bytes:
@@ -415,7 +422,10 @@ def _wgrad_candidates(g: Geom, bf16: bool = False, plain_operand: bool = False):
                     cands[(tile, s)] = min(1.0, tiles * s / (256 if cs == 128 else 512))
     # tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_glds.inc, conv_gemm_bf16_glds.inc)
     glds = (BF16_GLDS if bf16 else F32_GLDS and g.Cin % 4 == 0 and g.Cout % 4 == 0)
-    for tile, tsz in (((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))):
+    tile_list = ((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))
+    if glds and not bf16 and F32_SPLIT_BF16 and plain_operand:
+        tile_list += ((7, 128), (8, 64))        # fp32 tiles 5 / 6 with the products on the bf16 matrix pipe
+    for tile, tsz in tile_list:
         if tsz == 128 and (g.Cin <= 64 or g.Cout <= 64):
             continue
         tiles = -(-g.Cin // tsz) * -(-g.Cout // tsz) * g.taps
@@ -1102,7 +1112,11 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 130
+    names = [None] * 140
+    names[138], names[139] = "wgrad_gemm_f32_glds_kernel<128, false, 2, 1>", "wgrad_gemm_f32_glds_kernel<64, false, 4, 1>"
+    for i, tt in enumerate(("128, 128, 2, 2, {}, 2, 1", "128, 64, 2, 2, {}, 3, 1", "64, 64, 2, 2, {}, 4, 1", "256, 128, 4, 2, {}, 3, 1")):
+        for k, spec in enumerate((1, 3)):
+            names[130 + 2 * i + k] = f"gather_gemm_f32_glds_kernel<{tt.format(spec)}>"
     names[127], names[128], names[129] = "pw_front_fwd_f32_kernel<false>", "pw_front_fwd_f32_kernel<true>", "pw_front_bwd_f32_kernel"
     names[124], names[125], names[126] = "pw_front_fwd_bf16_kernel<64, false>", "pw_front_fwd_bf16_kernel<64, true>", "pw_front_bwd_bf16_kernel<64>"
     names[122], names[123] = "wgrad_parity_bf16_kernel<64, *>", "wgrad_parity_bf16_kernel<128, *>"
@@ -1110,8 +1124,8 @@ def _prof_kind_names():
         names[120 + m - 1] = f"wgrad_gemm_bf16_glds_kernel<128, false, true, {m}>"
     for i, (tt, st) in enumerate((("128", (2, 2)), ("64", (4, 2)))):
         for xf in (0, 1):
-            names[116 + 2 * i + xf] = f"wgrad_gemm_f32_glds_kernel<{tt}, {'true' if xf else 'false'}, {st[xf]}>"
-    for i, tt in enumerate(("128, 128, 2, 2, {}, 2", "128, 64, 2, 2, {}, 3", "64, 64, 2, 2, {}, 4", "256, 128, 4, 2, {}, 2")):
+            names[116 + 2 * i + xf] = f"wgrad_gemm_f32_glds_kernel<{tt}, {'true' if xf else 'false'}, {st[xf]}, 0>"
+    for i, tt in enumerate(("128, 128, 2, 2, {}, 2, 0", "128, 64, 2, 2, {}, 3, 0", "64, 64, 2, 2, {}, 4, 0", "256, 128, 4, 2, {}, 2, 0")):
         for spec in (1, 2, 3):
             names[104 + 3 * i + spec - 1] = f"gather_gemm_f32_glds_kernel<{tt.format(spec)}>"
     for i, tt in enumerate(("128", "64")):

@@ -221,8 +221,21 @@ def test_conv_every_launch_plan(name, g):
                 dwp = ops.conv_wgrad(xd, dyd, g)
             check(f"plan/{name}/wgrad_t{tile}s{split}", dw, dw_ref, rtol=5e-4, atol_rel=5e-4)
             check(f"plan/{name}/wgrad_plain_t{tile}s{split}", dwp, dwp_ref, rtol=5e-4, atol_rel=5e-4)
+    for tile in (7, 8):           # fp32 wgrad tiles 5 / 6 with the products on the bf16 matrix pipe: plain operand only
+        if g.Cin % 4 or g.Cout % 4:
+            continue
+        if tile == 7 and min(g.Cin, g.Cout) <= 64:
+            with ops.force_plan(7, 1), pytest.raises(ops.MopoeHipError):
+                ops.conv_wgrad(xd, dyd, g)
+            continue
+        for split in (1, 3, 64):
+            with ops.force_plan(tile, split):
+                dwp = ops.conv_wgrad(xd, dyd, g)
+            check(f"plan/{name}/wgrad_plain_t{tile}s{split}", dwp, dwp_ref, rtol=5e-4, atol_rel=5e-4)
+        with ops.force_plan(tile, 1), pytest.raises(ops.MopoeHipError):
+            ops.conv_wgrad(xd, dyd, g, bn_in=bnd)
     with pytest.raises(ops.MopoeHipError):
-        with ops.force_plan(16, 1):
+        with ops.force_plan(20, 1):
             ops.conv_fwd(xd, wd, g)
 
 
@@ -261,7 +274,7 @@ def test_conv_lds_dma_tiles(name, g):
     s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
     dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
     dx_plain = TB.conv_dgrad(dy, wp, g)
-    for tile in (12, 13, 14, 15):
+    for tile in (12, 13, 14, 15, 16, 17, 18, 19):     # 16..19: tiles 12..15 with the fp32 products on the bf16 matrix pipe
         for split in (1, 3):
             tag = f"glds/{name}/t{tile}s{split}"
             with ops.force_plan(tile, split):
@@ -270,7 +283,7 @@ def test_conv_lds_dma_tiles(name, g):
                     check(f"{tag}/fwd_shortcut", ops.conv_fwd(xd, wd, g, bias=bd, out_stats=st), y_short)
                     check(f"{tag}/fwd_shortcut_stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
                     check(f"{tag}/fwd_emask", ops.conv_fwd(xd, wd, g, bias=bd, mask=to_dev(emask)), y_emask)
-                    if tile != 13:
+                    if tile not in (13, 16, 17, 18, 19):
                         st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
                         check(f"{tag}/fwd_bn", ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bd, mask=to_dev(cmask), out_stats=st), y_x)
                         check(f"{tag}/fwd_bn_stats", st, stx_ref, rtol=1e-4, atol_rel=1e-4)
@@ -286,6 +299,58 @@ def test_conv_lds_dma_tiles(name, g):
                     check(f"{tag}/dgrad_relubn", ops.conv_dgrad(dyd, wd, g, relu_bn=bnd, xin=xd, bwd_sums=s), dx_ref)
                     check(f"{tag}/dgrad_sums", s, s_ref, rtol=2e-4, atol_rel=2e-4)
                     check(f"{tag}/dgrad", ops.conv_dgrad(dyd, wd, g), dx_plain)
+
+
+def _err64(y, ref64):
+    d = y.double() - ref64
+    return float(d.norm() / ref64.norm()), float(d.abs().max() / ref64.abs().max())
+
+
+@pytest.mark.parametrize("name,g", [
+    ("rb1_C64to128", Geom(4, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False)),
+    ("dec_T128to64", Geom(4, 16, 16, 32, 32, 128, 64, 4, 4, 2, 2, 1, 1, True)),
+    ("text_T512to512_k1x4", Geom(16, 1, 32, 1, 64, 512, 512, 1, 4, 1, 2, 0, 1, True)),
+    ("fc_1x1_320", Geom(64, 1, 1, 1, 1, 320, 320, 1, 1, 1, 1, 0, 0, False)),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_f32_products_on_the_bf16_pipe(name, g):
+    """plan tiles 16..19 / wgrad tiles 7, 8 (csrc/conv_gemm_glds.inc, EMU): every fp32 operand value split exactly into three
+    bf16 parts, six of the nine partial products accumulated in fp32 by the bf16 MFMA.  The claim tested: the result is an
+    fp32 result -- its error against an fp64 product of the SAME fp32 operands is no larger than that of the fp32-MFMA tiles
+    (v_mfma_f32_32x32x2_f32, tiles 12..15 / 5, 6), and a few 1e-7 relative.  Inputs with a wide dynamic range
+    (random signs, magnitudes over 2^+-12, a block of exact zeros) so that no part of the split is trivially empty."""
+    gen = torch.Generator().manual_seed(29)
+    def wide(shape):
+        t = torch.randn(shape, generator=gen) * torch.exp2(torch.randint(-12, 13, shape, generator=gen).float())
+        t.view(-1)[: t.numel() // 7] = 0.0
+        return t
+    for dist in ("normal", "wide"):
+        if dist == "normal":
+            x, dy = torch.randn(g.in_shape, generator=gen), torch.randn(g.out_shape, generator=gen)
+            wp = torch.randn(g.taps, g.Cin, g.Cout, generator=gen) / math.sqrt(g.taps * g.Cin)
+        else:
+            x, dy, wp = wide(g.in_shape), wide(g.out_shape), wide((g.taps, g.Cin, g.Cout))
+        xd, wd, dyd = x.to(DEV), wp.to(DEV), dy.to(DEV)
+        y64 = TB.conv_fwd(xd.double(), wd.double(), g)
+        dx64 = TB.conv_dgrad(dyd.double(), wd.double(), g)
+        dw64 = TB.conv_wgrad(xd.double(), dyd.double(), g)
+        err = {}
+        for tile in (12, 13, 14, 15, 16, 17, 18, 19):
+            with ops.force_plan(tile, 1):
+                err[("fwd", tile)] = _err64(ops.conv_fwd(xd, wd, g), y64)
+                err[("dgrad", tile)] = _err64(ops.conv_dgrad(dyd, wd, g), dx64)
+        wtiles = (6, 8) if min(g.Cin, g.Cout) <= 64 else (5, 6, 7, 8)
+        for tile in wtiles:
+            with ops.force_plan(tile, 1):
+                err[("wgrad", tile)] = _err64(ops.conv_wgrad(xd, dyd, g), dw64)
+        for (op, tile), (l2, mx) in sorted(err.items()):
+            _log(f"emu/{name}/{dist}/{op}/t{tile}: relL2 vs fp64 {l2:.3e}  max {mx:.3e}")
+        for op, pairs in (("fwd", ((16, 12), (17, 13), (18, 14), (19, 15))), ("dgrad", ((16, 12), (17, 13), (18, 14), (19, 15))),
+                          ("wgrad", tuple((a, b) for a, b in ((7, 5), (8, 6)) if a in wtiles))):
+            for emu, native in pairs:
+                l2e, mxe = err[(op, emu)]
+                l2n, mxn = err[(op, native)]
+                assert l2e <= 1.05 * l2n + 1e-9, (name, dist, op, emu, l2e, l2n)
+                assert l2e < 2e-6 and mxe < 1e-5, (name, dist, op, emu, l2e, mxe)
 
 
 def test_conv_large_rows_splitk_and_big_tiles():
