@@ -1168,7 +1168,7 @@ static int launch_gather(const float* X, const float* W, const float* bias, floa
     }
     if (cfg >= 3 && !vec) cfg = cfg == 3 ? 0 : 2;   // the extra tiles exist for the vector path only
     if ((cfg == 5 || cfg == 6) && Ck % 32 != 0) cfg -= 3;   // 5, 6 = tiles 2, 4 with a 32-deep K chunk
-    if (cfg >= 8 && (!vec || Ck % 8 != 0 || a.mix)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels
+    if (cfg >= 8 && cfg < 12 && (!vec || Ck % 8 != 0 || a.mix)) cfg = (cfg == 8) ? 0 : (cfg == 9 ? 1 : (cfg == 10 ? 2 : 4));   // 8..11 = LDS-free kernels (no residual mix)
   }
   static const int TILE_BM[16] = {128, 256, 64, 256, 128, 64, 128, 128, 128, 256, 64, 128, 128, 128, 64, 256};
   static const int TILE_BN[16] = {128, 64, 64, 128, 64, 64, 64, 128, 128, 64, 64, 64, 128, 64, 64, 128};

@@ -271,6 +271,8 @@ def test_conv_lds_dma_tiles(name, g):
     y_x = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=stx_ref)
     stm_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
     y_mix = TB.conv_fwd(x, wp, g, bn_in=bn, bias=bias, mask=cmask, out_stats=stm_ref, mix=(sres, bns))
+    stp_ref = torch.zeros(2, g.Cout, dtype=torch.float64)
+    y_mixp = TB.conv_fwd(x, wp, g, bias=bias, mask=cmask, out_stats=stp_ref, mix=(sres, bns))     # residual mix, plain operand
     s_ref = torch.zeros(2, g.Cin, dtype=torch.float64)
     dx_ref = TB.conv_dgrad(dy, wp, g, relu_bn=bn, xin=x, bwd_sums=s_ref)
     dx_plain = TB.conv_dgrad(dy, wp, g)
@@ -283,6 +285,10 @@ def test_conv_lds_dma_tiles(name, g):
                     check(f"{tag}/fwd_shortcut", ops.conv_fwd(xd, wd, g, bias=bd, out_stats=st), y_short)
                     check(f"{tag}/fwd_shortcut_stats", st, st_ref, rtol=1e-4, atol_rel=1e-4)
                     check(f"{tag}/fwd_emask", ops.conv_fwd(xd, wd, g, bias=bd, mask=to_dev(emask)), y_emask)
+                    st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
+                    check(f"{tag}/fwd_mix_plain", ops.conv_fwd(xd, wd, g, bias=bd, mask=to_dev(cmask), out_stats=st,
+                                                               mix=(sres.to(DEV), to_dev(bns))), y_mixp)
+                    check(f"{tag}/fwd_mix_plain_stats", st, stp_ref, rtol=1e-4, atol_rel=1e-4)
                     if tile not in (13, 16, 17, 18, 19):
                         st = torch.zeros(2, g.Cout, dtype=torch.float64, device=DEV)
                         check(f"{tag}/fwd_bn", ops.conv_fwd(xd, wd, g, bn_in=bnd, bias=bd, mask=to_dev(cmask), out_stats=st), y_x)

@@ -75,12 +75,15 @@ def main():
         reports[cfg] = d["report"]
         print(f"[plans] {cfg}: {len(d['plans'])} triples, {new} new", flush=True)
         os.remove(tmp)
+    configs = list(args.configs)
     if args.merge and os.path.exists(args.merge):
         with open(args.merge) as f:
-            for k, v in json.load(f).get("plans", {}).items():
-                plans.setdefault(k, v)
+            old = json.load(f)
+        for k, v in old.get("plans", {}).items():
+            plans.setdefault(k, v)
+        configs += [c for c in old.get("meta", {}).get("configs", []) if c not in configs]   # the kept triples' configurations
     import torch
-    meta = {"device": "MI355X (gfx950)", "torch": torch.__version__, "configs": args.configs,
+    meta = {"device": "MI355X (gfx950)", "torch": torch.__version__, "configs": configs,
             "note": "written by tests/tools/make_plan_table.py; key = op|geometry(N,Hs,Ws,Hb,Wb,Cin,Cout,kh,kw,sh,sw,ph,pw,transposed)|fusion flags; "
                     "value = [tile, split] (include/mopoe_hip.h: mopoe_conv_plan) or null = the library's static heuristic"}
     with open(args.out, "w") as f:
