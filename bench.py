@@ -50,6 +50,12 @@ CONFIGS = {
 }
 # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" 157.3 TF; bf16 MFMA ~2.5 PF dense; HBM3E ~8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def _on_bf16_pipe(kernel_name: str) -> bool:
+    """fp32-family kernels whose products run on the bf16 matrix pipe (csrc/conv_gemm_glds.inc, EMU = 1: plan tiles 16..19 /
+    wgrad tiles 7, 8) -- their template name ends with ', 1>'"""
+    return ("gather_gemm_f32_glds_kernel<" in kernel_name or "wgrad_gemm_f32_glds_kernel<" in kernel_name) and kernel_name.endswith(", 1>")
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 # SURVEY.md §8(d): conv/linear FLOPs per sample per train step (fwd + dgrad + wgrad) and algorithmic bytes per sample
@@ -359,8 +365,16 @@ def main():
                                              "per_kernel_ms_per_step": {k: round(v[1] / nprof, 3) for k, v in prof.items()}}}
         elif n:
             achieved = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            # a kernel that computes its fp32 products on the bf16 matrix pipe (template argument EMU = 1: six
+            # v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block of fp32 products) is priced against THAT pipe: 2.5 PF / 6
+            split = _on_bf16_pipe(name)
+            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            split_ms = sum(v[1] for k, v in prof.items() if _on_bf16_pipe(k))
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": round(peak, 1),
+                        "peak_source": ("bf16 MFMA dense peak / 6 (six bf16 MFMAs per block of fp32 products)" if split
+                                        else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "gemm_time_on_bf16_pipe": round(split_ms / all_ms, 3) if all_ms else None,
                         "traffic_source": (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc passes of an earlier run, not measured in this one)") if traffic is not None else None,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                         "flops_per_launch": fl / n, "bytes_per_launch": by / n,
@@ -387,7 +401,11 @@ def main():
                                    f"(PA+Lateral+text) {size}x{size}, class_dim {cdim}, DIM_img {dimg}, DIM_text 128, "
                                    f"vocab 3517, batch {bsz}/GPU, "
                                    + ("bf16 storage + bf16 MFMA with fp32 accumulation (fp32 statistics, latent kernel, "
-                                      "likelihoods, master weights, Adam)" if cdtype == "bf16" else "fp32")
+                                      "likelihoods, master weights, Adam)" if cdtype == "bf16"
+                                      else "fp32 (storage, accumulation and every product; where the launch plan says so the "
+                                           "fp32 products are formed on the bf16 matrix pipe from exact three-way splits of "
+                                           "both operands -- closer to fp64 than the fp32 MFMA, tests: "
+                                           "test_f32_products_on_the_bf16_pipe; MOPOE_F32_SPLIT_BF16=0 turns it off)")
                                    + ", BatchNorm batch stats + dropout, Adam",
                        "global_batch": bsz * world, "parallelism": f"dp{world}",
                        "elbo_iters_per_sec": round(args.steps / elapsed, 3),

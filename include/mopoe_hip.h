@@ -462,7 +462,7 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   127..129 pw_front_fwd_f32_kernel<false>, <true>, pw_front_bwd_f32_kernel
  *   130..137 gather_gemm_f32_glds_kernel<..., EMU = 1> (fp32 tiles 16..19): (tile - 16) * 2 + (input gradient ? 1 : 0)
  *   138..139 wgrad_gemm_f32_glds_kernel<..., EMU = 1> (fp32 wgrad tiles 7, 8) */
-#define MOPOE_PROF_KINDS 140
+#define MOPOE_PROF_KINDS 142
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

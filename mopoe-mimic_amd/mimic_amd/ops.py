@@ -297,6 +297,12 @@ def _table_plan(key):
     v = _plan_table.get(plan_key_str(key), False)
     if v is False:
         return False, None
+    if v is not None and not F32_SPLIT_BF16:
+        # the switch is off: a committed plan on the bf16 matrix pipe falls back to the same tile on the fp32 MFMA
+        if key[0] in ("fwd", "dgrad") and v[0] >= 16:
+            v = [v[0] - 4, v[1]]
+        elif key[0] == "wgrad" and v[0] in (7, 8):
+            v = [v[0] - 2, v[1]]
     return True, (None if v is None else _Plan(int(v[0]), int(v[1])))
 
 
@@ -1112,7 +1118,8 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 140
+    names = [None] * 142
+    names[140], names[141] = "wgrad_parity_f32_kernel<true>", "wgrad_parity_f32_kernel<false>"
     names[138], names[139] = "wgrad_gemm_f32_glds_kernel<128, false, 2, 1>", "wgrad_gemm_f32_glds_kernel<64, false, 4, 1>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2, 1", "128, 64, 2, 2, {}, 3, 1", "64, 64, 2, 2, {}, 4, 1", "256, 128, 4, 2, {}, 3, 1")):
         for k, spec in enumerate((1, 3)):

@@ -99,3 +99,33 @@ def test_committed_plan_table_is_well_formed():
     assert found
     found, _ = ops._table_plan(("fwd", ops.Geom(3, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False), False, False, True))
     assert not found
+
+
+def test_split_bf16_switch_maps_committed_plans_back(monkeypatch):
+    """MOPOE_F32_SPLIT_BF16=0: a committed fp32 plan on the bf16 matrix pipe (tiles 16..19, wgrad 7 / 8) is launched as the same
+    tile on the fp32 MFMA (12..15, 5 / 6); bf16-family plans are untouched"""
+    import json
+    from mimic_amd import ops
+    with open(ops.PLAN_TABLE_PATH) as f:
+        plans = json.load(f)["plans"]
+    ops._table_plan(("fwd", ops.Geom(64, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False), False, False, True))   # loads the table
+    def lookup(key_str):
+        v = ops._plan_table[key_str]
+        op = key_str.split("|")[0]
+        class K(tuple):
+            pass
+        # _table_plan needs the structured key only through plan_key_str: patch that to hand back the string
+        monkeypatch.setattr(ops, "plan_key_str", lambda key: key_str)
+        found, p = ops._table_plan((op,))
+        assert found
+        return v, p
+    on_pipe = [k for k, v in plans.items() if v is not None and ((k.split("|")[0] in ("fwd", "dgrad") and v[0] >= 16)
+                                                               or (k.split("|")[0] == "wgrad" and v[0] in (7, 8)))]
+    assert on_pipe, "the committed table holds no plan on the bf16 matrix pipe"
+    monkeypatch.setattr(ops, "F32_SPLIT_BF16", False)
+    for k in on_pipe[:20]:
+        v, p = lookup(k)
+        assert p.tile == (v[0] - 4 if k.split("|")[0] != "wgrad" else v[0] - 2) and p.split == v[1], (k, v, p.tile)
+    k16 = next(k for k, v in plans.items() if k.startswith("wgrad16") and v is not None and v[0] in (7, 8))
+    v, p = lookup(k16)
+    assert p.tile == v[0]

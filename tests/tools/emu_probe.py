@@ -78,7 +78,7 @@ def main():
                         dw = ops.conv_wgrad(xd[:nb].contiguous(), dyd[:nb].contiguous(), gs)
                     tw = None
                     best = None
-                    for sp in (16, 32, 64, 128, 256):
+                    for sp in (8, 16, 32, 64, 128, 256):
                         with ops.force_plan(tile, sp):
                             t = timed(lambda: ops.conv_wgrad(xd, dyd, g))
                         if best is None or t < best[0]:
@@ -90,6 +90,6 @@ def main():
                 print(f"  wgrad tile {tile:2d}  {best[0]:7.1f} us (split {best[1]}) {flops / best[0] / 1e6:6.1f} TF/s  relL2 {ew[0]:.2e} max {ew[1]:.2e}")
 
 
-WG_TILES = tuple(int(t) for t in os.environ.get("WG_TILES", "0,2,5,6,7,8").split(","))
+WG_TILES = tuple(int(t) for t in os.environ.get("WG_TILES", "2,6,8,9").split(","))
 if __name__ == "__main__":
     main()
