@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPOE_ABI_VERSION 18
+#define MOPOE_ABI_VERSION 19
 
 /* error codes */
 #define MOPOE_OK 0
@@ -116,6 +116,10 @@ size_t mopoe_conv_workspace_bytes(void);
  *   tile  -1 auto | 0 = 128x128 | 2 = 64x64 (Cin x Cout tile of one tap, register-staged, 16 pixels per chunk)
  *          | 5 = 128x128, 6 = 64x64 on LDS-DMA (32 pixels per stage; channel counts % 4 == 0; 5 needs > 64 channels on both sides)
  *          | 7, 8 = tiles 5, 6 with the fp32 products on the bf16 matrix pipe (as tiles 16..19 above; plain operand only)
+ *          | 9, 10 = FOUR taps (one parity class of a k4 s2 p1 kernel) per block, 64 gathered channels x 64 / 128 channels of the
+ *            small-grid operand, products on the bf16 matrix pipe (csrc/conv_gemm_glds_parity.inc; plain operand; channel counts
+ *            % 4 == 0; small grid of whole 8 x 8 tiles; 10 needs a multiple of 128 channels there); split = blocks sharing the
+ *            pixel TILES
  *   split  0 auto | n >= 1 blocks sharing one tile's pixel reduction (atomics into dwp)
  * bf16 family (mopoe_conv_fwd_bf16 / _fwd_mix_bf16 / _dgrad_bf16):
  *   tile  -1 auto | 0 = 128x128 | 1 = 256x64 | 2 = 64x64 | 3 = 256x128 | 4 = 128x64 (register-staged, 32-deep K chunk)
@@ -461,8 +465,9 @@ int mopoe_adam_step(const mopoe_adam_seg* segs, int32_t nseg, float* step, const
  *   124..126 pw_front_fwd_bf16_kernel<64, false> (statistics pass), <64, true> (a2 pass), pw_front_bwd_bf16_kernel<64>
  *   127..129 pw_front_fwd_f32_kernel<false>, <true>, pw_front_bwd_f32_kernel
  *   130..137 gather_gemm_f32_glds_kernel<..., EMU = 1> (fp32 tiles 16..19): (tile - 16) * 2 + (input gradient ? 1 : 0)
- *   138..139 wgrad_gemm_f32_glds_kernel<..., EMU = 1> (fp32 wgrad tiles 7, 8) */
-#define MOPOE_PROF_KINDS 142
+ *   138..139 wgrad_gemm_f32_glds_kernel<..., EMU = 1> (fp32 wgrad tiles 7, 8)
+ *   140..143 wgrad_parity_f32_kernel<CS, conv ? true : false> (fp32 wgrad tiles 9 / 10): (CS == 128 ? 2 : 0) + (transposed ? 1 : 0) */
+#define MOPOE_PROF_KINDS 144
 int mopoe_prof_enable(int32_t on);
 /* Device timestamp (ticks of the 100 MHz constant clock) written to *slot when `stream` reaches this point: a one-thread
  * kernel, so it can be captured into a hipGraph -- the only way to see WHEN the branches of a replayed graph run without

@@ -109,7 +109,7 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 //   fp32 wgrad, LDS-DMA:  116 + (128x128 ? 0 : 2) + (BN+ReLU on x ? 1 : 0)         kinds 116..119
 //   fp32 gather, LDS-DMA, products on the bf16 pipe: 130 + (tile - 16) * 2 + (input gradient ? 1 : 0)   kinds 130..137
 //   fp32 wgrad,  LDS-DMA, products on the bf16 pipe: 138 + (128x128 ? 0 : 1)       kinds 138..139
-//   fp32 wgrad, four taps per block, products on the bf16 pipe (tile 9)            kinds 140..141 (conv / transposed conv)
+//   fp32 wgrad, four taps per block, products on the bf16 pipe (tile 9)            kinds 140..143: (S tile 128 ? 2 : 0) + (transposed conv ? 1 : 0)
 enum { PROF_GATHER_VEC = 0, PROF_GATHER_SCALAR = 32, PROF_WGRAD_VEC = 36, PROF_WGRAD_SCALAR = 42, PROF_DIRECT = 44,
        PROF_BF16_GATHER = 60, PROF_BF16_WGRAD = 75, PROF_BF16_GLDS = 80, PROF_BF16_GLDS_X = 94, PROF_BF16_WGRAD_GLDS = 100, PROF_F32_GLDS = 104, PROF_F32_WGRAD_GLDS = 116, PROF_BF16_WGRAD_GLDS_MERGE = 120, PROF_BF16_WGRAD_PARITY = 122, PROF_PW_FRONT = 124, PROF_F32_GLDS_EMU = 130, PROF_F32_WGRAD_GLDS_EMU = 138, PROF_F32_WGRAD_PARITY = 140, PROF_NKINDS = MOPOE_PROF_KINDS };
 struct ProfScope {

@@ -1374,16 +1374,18 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
   // stage: conv_gemm_glds.inc; vector path only)
   // 9 = four taps (one parity class of a k4 s2 p1 kernel) per block, 64 x 64 channels, products on the bf16 matrix pipe
   // (conv_gemm_glds_parity.inc: wgrad_parity_f32_kernel)
-  if (plan && plan->tile == 9) {
+  if (plan && (plan->tile == 9 || plan->tile == 10)) {
     const bool ok = a.bn_in.mode == 0 && vec && g->kh == 4 && g->kw == 4 && g->sh == 2 && g->sw == 2 && g->ph == 1 && g->pw == 1 &&
                     g->Hs % 8 == 0 && g->Ws % 8 == 0 && g->Hb == 2 * g->Hs && g->Wb == 2 * g->Ws;
     if (!ok) {
-      set_error("wgrad plan: tile 9 (four taps per block) needs a plain operand, the vector path, k4 s2 p1 and a small grid of whole 8 x 8 tiles");
+      set_error("wgrad plan: tiles 9 / 10 (four taps per block) need a plain operand, the vector path, k4 s2 p1 and a small grid of whole 8 x 8 tiles");
       return MOPOE_ERR_ARG;
     }
     const int Cg = a.x_is_big ? g->Cin : g->Cout, Csm = a.x_is_big ? g->Cout : g->Cin;
+    const int cs = plan->tile == 10 ? 128 : 64;
+    if (cs == 128 && Csm % 128 != 0) { set_error("wgrad plan: tile 10 needs a multiple of 128 channels on the small-grid operand (%d)", Csm); return MOPOE_ERR_ARG; }
     const long ntiles = (long)g->N * (g->Hs / 8) * (g->Ws / 8);
-    const long cblocks = (long)ceil_div(Cg, 64) * ceil_div(Csm, 64) * 4;
+    const long cblocks = (long)ceil_div(Cg, 64) * ceil_div(Csm, cs) * 4;
     long split = plan->split > 0 ? plan->split : (256 + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
@@ -1395,10 +1397,12 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
     if (a.atomic && !dwp_is_zero) {
       if (hipMemsetAsync(dwp, 0, (size_t)taps * g->Cin * g->Cout * sizeof(float), stream) != hipSuccess) { set_error("wgrad memset failed"); return MOPOE_ERR_LAUNCH; }
     }
-    ProfScope prof(stream, 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps, PROF_F32_WGRAD_PARITY + (a.x_is_big ? 0 : 1), (double)xb + (double)db);
-    const dim3 grid((unsigned)(ceil_div(Cg, 64) * ceil_div(Csm, 64)), 4, (unsigned)split);
-    if (a.x_is_big) hipLaunchKernelGGL((wgrad_parity_f32_kernel<true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((wgrad_parity_f32_kernel<false>), grid, dim3(256), 0, stream, a);
+    ProfScope prof(stream, 2.0 * (double)a.Ms * g->Cin * (double)g->Cout * taps, PROF_F32_WGRAD_PARITY + (cs == 128 ? 2 : 0) + (a.x_is_big ? 0 : 1), (double)xb + (double)db);
+    const dim3 grid((unsigned)(ceil_div(Cg, 64) * ceil_div(Csm, cs)), 4, (unsigned)split);
+    if (cs == 128 && a.x_is_big) hipLaunchKernelGGL((wgrad_parity_f32_kernel<128, true>), grid, dim3(256), 0, stream, a);
+    else if (cs == 128) hipLaunchKernelGGL((wgrad_parity_f32_kernel<128, false>), grid, dim3(256), 0, stream, a);
+    else if (a.x_is_big) hipLaunchKernelGGL((wgrad_parity_f32_kernel<64, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_parity_f32_kernel<64, false>), grid, dim3(256), 0, stream, a);
     return check_launch("wgrad_parity_f32 (four taps per block)");
   }
   // 7, 8 = tiles 5, 6 with the fp32 products on the bf16 matrix pipe (EMU; plain operand only)
@@ -1409,7 +1413,7 @@ extern "C" int mopoe_conv_wgrad(const float* x, const float* dy, float* dwp, con
     // (mirrors the tuner, mimic_amd/ops.py: _wgrad_candidates -- the 128 tile is never offered with <= 64 channels on a side)
     if (!big) { set_error("wgrad plan: tile %d (128x128 on LDS-DMA) needs more than 64 channels on both sides (%d, %d)", plan->tile, g->Cin, g->Cout); return MOPOE_ERR_ARG; }
   }
-  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6, 7, 8, 9)", plan->tile); return MOPOE_ERR_ARG; }
+  else if (plan && plan->tile > 2) { set_error("wgrad plan: tile %d (see mopoe_conv_plan in mopoe_hip.h: -1, 0, 2, 5, 6, 7, 8, 9, 10)", plan->tile); return MOPOE_ERR_ARG; }
   const bool glds = plan && plan->tile >= 5;
   if (glds && !vec) { set_error("wgrad plan: the LDS-DMA tiles need the vector path (channel counts %% 4 == 0, aligned tensors)"); return MOPOE_ERR_ARG; }
   const int T = big ? 128 : 64;

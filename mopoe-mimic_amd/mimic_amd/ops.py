@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPOE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmopoe_hip.so")  # env override: A/B builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 RES_A, RES_B = 2.0, 0.3
 BN_EPS = 1e-5
@@ -303,6 +303,8 @@ def _table_plan(key):
             v = [v[0] - 4, v[1]]
         elif key[0] == "wgrad" and v[0] in (7, 8):
             v = [v[0] - 2, v[1]]
+        elif key[0] == "wgrad" and v[0] in (9, 10):
+            v = [2, v[1]]
     return True, (None if v is None else _Plan(int(v[0]), int(v[1])))
 
 
@@ -426,6 +428,22 @@ def _wgrad_candidates(g: Geom, bf16: bool = False, plain_operand: bool = False):
                 if s not in seen:
                     seen.add(s)
                     cands[(tile, s)] = min(1.0, tiles * s / (256 if cs == 128 else 512))
+    # fp32 tiles 9 / 10 (plain operand, k4 s2 p1, small grid of whole 8 x 8 tiles): four taps per block with the products on the
+    # bf16 matrix pipe (csrc/conv_gemm_glds_parity.inc); 64 gathered channels x 64 / 128 channels of the small-grid operand
+    if (not bf16 and F32_GLDS and F32_SPLIT_BF16 and plain_operand and (g.kh, g.kw, g.sh, g.sw, g.ph, g.pw) == (4, 4, 2, 2, 1, 1)
+            and g.Hs % 8 == 0 and g.Ws % 8 == 0 and g.Hb == 2 * g.Hs and g.Wb == 2 * g.Ws and g.Cin % 4 == 0 and g.Cout % 4 == 0):
+        cg, csm = (g.Cout, g.Cin) if g.transposed else (g.Cin, g.Cout)
+        ntiles = g.N * (g.Hs // 8) * (g.Ws // 8)
+        for tile, cs in ((9, 64), (10, 128)):
+            if csm % cs:
+                continue
+            tiles = -(-cg // 64) * (csm // cs) * 4
+            seen = set()
+            for target in (64, 128, 192, 256, 384, 512, 1024):
+                s = max(1, min(-(-target // tiles), ntiles))
+                if s not in seen:
+                    seen.add(s)
+                    cands[(tile, s)] = min(1.0, tiles * s / 256)
     # tiles 5 / 6 = the 128 / 64 tiles on LDS-DMA (csrc/conv_gemm_glds.inc, conv_gemm_bf16_glds.inc)
     glds = (BF16_GLDS if bf16 else F32_GLDS and g.Cin % 4 == 0 and g.Cout % 4 == 0)
     tile_list = ((0, 128), (2, 64), (5, 128), (6, 64)) if glds else ((0, 128), (2, 64))
@@ -1118,8 +1136,9 @@ _TILE_TEMPLATES = ("128, 128, 2, 4, 16", "256, 64, 4, 2, 16", "64, 64, 2, 2, 16"
 
 def _prof_kind_names():
     """kind index -> the kernel's template name exactly as rocprofv3 prints it (header: MOPOE_PROF_KINDS)"""
-    names = [None] * 142
-    names[140], names[141] = "wgrad_parity_f32_kernel<true>", "wgrad_parity_f32_kernel<false>"
+    names = [None] * 144
+    names[140], names[141] = "wgrad_parity_f32_kernel<64, true>", "wgrad_parity_f32_kernel<64, false>"
+    names[142], names[143] = "wgrad_parity_f32_kernel<128, true>", "wgrad_parity_f32_kernel<128, false>"
     names[138], names[139] = "wgrad_gemm_f32_glds_kernel<128, false, 2, 1>", "wgrad_gemm_f32_glds_kernel<64, false, 4, 1>"
     for i, tt in enumerate(("128, 128, 2, 2, {}, 2, 1", "128, 64, 2, 2, {}, 3, 1", "64, 64, 2, 2, {}, 4, 1", "256, 128, 4, 2, {}, 3, 1")):
         for k, spec in enumerate((1, 3)):

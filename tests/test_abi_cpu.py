@@ -91,7 +91,7 @@ def test_committed_plan_table_is_well_formed():
         op, geo, _flags = key.split("|")
         assert op in ("fwd", "dgrad", "wgrad", "fwd16", "dgrad16", "wgrad16"), key
         assert len(geo.split(",")) == 14 and all(x.lstrip("-").isdigit() for x in geo.split(",")), key
-        top = {"fwd": 19, "dgrad": 19, "wgrad": 8, "fwd16": 11, "dgrad16": 11, "wgrad16": 9}[op]     # the header's tile ranges
+        top = {"fwd": 19, "dgrad": 19, "wgrad": 10, "fwd16": 11, "dgrad16": 11, "wgrad16": 9}[op]     # the header's tile ranges
         assert v is None or (len(v) == 2 and 0 <= v[0] <= top and 1 <= v[1] <= 4096), (key, v)
     # rb1's shortcut conv at config #2 (B = 64): forward, no BN on load, no mask, statistics
     g = ops.Geom(64, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False)
@@ -120,12 +120,13 @@ def test_split_bf16_switch_maps_committed_plans_back(monkeypatch):
         assert found
         return v, p
     on_pipe = [k for k, v in plans.items() if v is not None and ((k.split("|")[0] in ("fwd", "dgrad") and v[0] >= 16)
-                                                               or (k.split("|")[0] == "wgrad" and v[0] in (7, 8)))]
+                                                               or (k.split("|")[0] == "wgrad" and v[0] in (7, 8, 9, 10)))]
     assert on_pipe, "the committed table holds no plan on the bf16 matrix pipe"
     monkeypatch.setattr(ops, "F32_SPLIT_BF16", False)
     for k in on_pipe[:20]:
         v, p = lookup(k)
-        assert p.tile == (v[0] - 4 if k.split("|")[0] != "wgrad" else v[0] - 2) and p.split == v[1], (k, v, p.tile)
+        want = v[0] - 4 if k.split("|")[0] != "wgrad" else (v[0] - 2 if v[0] in (7, 8) else 2)
+        assert p.tile == want and p.split == v[1], (k, v, p.tile)
     k16 = next(k for k, v in plans.items() if k.startswith("wgrad16") and v is not None and v[0] in (7, 8))
     v, p = lookup(k16)
     assert p.tile == v[0]

@@ -364,6 +364,7 @@ PARITY_GEOMS32 = [
     ("enc_128to192_b5", Geom(5, 8, 8, 16, 16, 128, 192, 4, 4, 2, 2, 1, 1, False)),      # two G tiles, three S tiles
     ("enc_64to64_b2", Geom(2, 8, 16, 16, 32, 64, 64, 4, 4, 2, 2, 1, 1, False)),         # non-square map
     ("enc_72to136_b2", Geom(2, 8, 8, 16, 16, 72, 136, 4, 4, 2, 2, 1, 1, False)),        # partial channel tiles on both sides
+    ("enc_64to256_b2", Geom(2, 8, 8, 16, 16, 64, 256, 4, 4, 2, 2, 1, 1, False)),        # two S tiles of 128
     ("dec_128to64_b5", Geom(5, 8, 8, 16, 16, 128, 64, 4, 4, 2, 2, 1, 1, True)),         # transposed: G = dy (64), S = x (128)
     ("dec_64to64_b3", Geom(3, 16, 16, 32, 32, 64, 64, 4, 4, 2, 2, 1, 1, True)),         # transposed
     ("dec_192to128_b2", Geom(2, 8, 8, 16, 16, 192, 128, 4, 4, 2, 2, 1, 1, True)),       # transposed, two G tiles
@@ -372,7 +373,7 @@ PARITY_GEOMS32 = [
 
 @pytest.mark.parametrize("name,g", PARITY_GEOMS32, ids=[n for n, _ in PARITY_GEOMS32])
 def test_wgrad_four_taps_per_block_f32(name, g):
-    """fp32 wgrad tile 9 (csrc/conv_gemm_glds_parity.inc): one parity class of a k4 s2 p1 kernel -- four taps -- per block, the
+    """fp32 wgrad tiles 9 / 10 (csrc/conv_gemm_glds_parity.inc): one parity class of a k4 s2 p1 kernel -- four taps -- per block, the
     9 x 9 big-grid pixels of an 8 x 8 tile of small-grid pixels staged once for all of them, the fp32 products on the bf16
     matrix pipe: every tap of every class against the emulation AND against fp64 (no further from it than the fp32-MFMA
     tile 2), with and without a split of the pixel tiles; refused with BN on load, for other kernel shapes and for maps that
@@ -385,13 +386,19 @@ def test_wgrad_four_taps_per_block_f32(name, g):
     ref64 = TB.conv_wgrad(xd.double(), dyd.double(), g)
     with ops.force_plan(2, 1):
         e_native = _err64(ops.conv_wgrad(xd, dyd, g), ref64)
-    for split in (1, 2, 5):
-        with ops.force_plan(9, split):
-            dw = ops.conv_wgrad(xd, dyd, g)
-        check(f"{name}/wgrad_t9s{split}", dw, ref, rtol=3e-4, atol_rel=3e-4)
-        e = _err64(dw, ref64)
-        _log(f"parity32/{name}/s{split}: relL2 vs fp64 {e[0]:.3e} (tile 2: {e_native[0]:.3e})")
-        assert e[0] <= 1.05 * e_native[0] + 1e-9, (name, split, e, e_native)
+    csm = g.Cin if g.transposed else g.Cout
+    for tile in (9, 10):          # 10: S tile of 128 channels (a wave owns all four taps)
+        if tile == 10 and csm % 128:
+            with ops.force_plan(10, 1), pytest.raises(ops.MopoeHipError):
+                ops.conv_wgrad(xd, dyd, g)
+            continue
+        for split in (1, 2, 5):
+            with ops.force_plan(tile, split):
+                dw = ops.conv_wgrad(xd, dyd, g)
+            check(f"{name}/wgrad_t{tile}s{split}", dw, ref, rtol=3e-4, atol_rel=3e-4)
+            e = _err64(dw, ref64)
+            _log(f"parity32/{name}/t{tile}s{split}: relL2 vs fp64 {e[0]:.3e} (tile 2: {e_native[0]:.3e})")
+            assert e[0] <= 1.05 * e_native[0] + 1e-9, (name, tile, split, e, e_native)
     with ops.force_plan(9, 1):
         bn = make_bn(g.Cin, x.numel() // g.Cin, 1, gen, x)
         with pytest.raises(ops.MopoeHipError):
