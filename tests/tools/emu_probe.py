@@ -58,7 +58,7 @@ def main():
         dw64 = TB.conv_wgrad(xd[:nb].double(), dyd[:nb].double(), gs)
         flops = 2.0 * math.prod(g.out_shape[:3]) * g.Cout * g.Cin * g.taps / (g.sh * g.sw if g.transposed else 1)
         print(f"== {name}  N={g.N}  {flops / 1e9:.1f} GF")
-        for tile in (12, 13, 14, 15, 16, 17, 18, 19):
+        for tile in TILES:
             try:
                 with ops.force_plan(tile, 1):
                     y = ops.conv_fwd(xd[:nb].contiguous(), wd, gs)
@@ -90,6 +90,7 @@ def main():
                 print(f"  wgrad tile {tile:2d}  {best[0]:7.1f} us (split {best[1]}) {flops / best[0] / 1e6:6.1f} TF/s  relL2 {ew[0]:.2e} max {ew[1]:.2e}")
 
 
+TILES = tuple(int(t) for t in os.environ.get("TILES", "12,13,14,15,16,17,18,19,20,21").split(","))
 WG_TILES = tuple(int(t) for t in os.environ.get("WG_TILES", "2,6,8,9").split(","))
 if __name__ == "__main__":
     main()
