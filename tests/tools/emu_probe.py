@@ -90,7 +90,7 @@ def main():
                 print(f"  wgrad tile {tile:2d}  {best[0]:7.1f} us (split {best[1]}) {flops / best[0] / 1e6:6.1f} TF/s  relL2 {ew[0]:.2e} max {ew[1]:.2e}")
 
 
-TILES = tuple(int(t) for t in os.environ.get("TILES", "12,13,14,15,16,17,18,19,20,21").split(","))
+TILES = tuple(int(t) for t in os.environ.get("TILES", "12,13,14,15,16,17,18,19").split(","))
 WG_TILES = tuple(int(t) for t in os.environ.get("WG_TILES", "2,6,8,9").split(","))
 if __name__ == "__main__":
     main()
