@@ -332,6 +332,15 @@ def main():
             torch.cuda.synchronize()
             prof = ops.prof_collect()
             ops.prof_enable(False)
+        # what the bracket itself costs: HIP-event pairs with nothing between them on the same stream (a launch's bracket adds
+        # part of this to the kernel's own duration, which is what rocprofv3 reports: profiles/README.md)
+        with torch.cuda.stream(prof_stream):
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+            for e0, e1 in pairs:
+                e0.record()
+                e1.record()
+            torch.cuda.synchronize()
+            empty_pair_us = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[32] * 1e3
         name, (n, ms, fl, by) = max(prof.items(), key=lambda kv: kv[1][1])
         all_ms = sum(v[1] for v in prof.values())
         all_fl = sum(v[2] for v in prof.values())
@@ -356,6 +365,7 @@ def main():
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc passes of an earlier run, not measured in this one)") if traffic is not None else None,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
+                        "empty_event_pair_us": round(empty_pair_us, 2),
                         "bytes_per_launch": by / n, "flops_per_launch": fl / n,
                         "mfma_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                         "mfma_frac_of_bf16_peak": round(fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -377,6 +387,7 @@ def main():
                         "gemm_time_on_bf16_pipe": round(split_ms / all_ms, 3) if all_ms else None,
                         "traffic_source": (os.path.relpath(pmc_file, REPO) + " (rocprofv3 --pmc passes of an earlier run, not measured in this one)") if traffic is not None else None,
                         "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
+                        "empty_event_pair_us": round(empty_pair_us, 2),
                         "flops_per_launch": fl / n, "bytes_per_launch": by / n,
                         "algorithmic_gbs": round(by / (ms * 1e-3) / 1e9, 1),
                         "all_gemm_kernels": {"ms_per_step": round(all_ms / nprof, 3),
