@@ -242,7 +242,10 @@ class _Plan(C.Structure):
 # is launched a few times on scratch accumulators, timed with events on the current stream, and the fastest is
 # kept for the life of the process.  All plans compute the same sums (in a different association order).
 # MOPOE_AUTOTUNE=0 keeps the static heuristic (plan = NULL).
-AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") != "0"
+AUTOTUNE = os.environ.get("MOPOE_AUTOTUNE", "1") not in ("0", "table")
+# MOPOE_AUTOTUNE=table: the committed plans where the table has the triple, the static heuristic elsewhere, no timing at all
+# (the GPU tests of the BASELINE shapes run in this mode: the kernels the product launches, without a tuner pass per test)
+TABLE_ONLY = os.environ.get("MOPOE_AUTOTUNE", "1") == "table"
 _TUNE_REPS = int(os.environ.get("MOPOE_TUNE_REPS", "3"))
 # Optional: leave the first N conv launches of the process on the static heuristic and start tuning afterwards
 # (a GPU that has just left idle ranks candidates differently from steady state).  Default 0 = tune at first use,
@@ -295,6 +298,10 @@ def _table_plan(key):
             with open(PLAN_TABLE_PATH) as f:
                 _plan_table = json.load(f).get("plans", {})
     v = _plan_table.get(plan_key_str(key), False)
+    if v is False and key[0] in ("fwd", "fwd16") and len(key) >= 4 and isinstance(key[3], bool):
+        # a forward conv with / without a dropout mask in its epilogue (train / eval, or dropout disabled): the table was measured
+        # on the training step; the mask multiplies the finished tile and does not move the choice of tile or split
+        v = _plan_table.get(plan_key_str(key[:3] + (not key[3],) + key[4:]), False)
     if v is False:
         return False, None
     if v is not None and not F32_SPLIT_BF16:
@@ -482,13 +489,17 @@ def _tuned_plan(key, cands_fn, launch):
     if key in _plans:
         p = _plans[key]
         return None if p is None else C.byref(p)
-    if not AUTOTUNE:
+    if not AUTOTUNE and not TABLE_ONLY:
         return None
     found, p = _table_plan(key)
     if found:
         _plans[key] = p
         _plan_sources["table"] += 1
         return None if p is None else C.byref(p)
+    if TABLE_ONLY and not AUTOTUNE:
+        _plans[key] = None
+        _plan_sources["static"] += 1
+        return None
     if torch.cuda.is_current_stream_capturing():
         return None
     global _conv_calls

@@ -67,6 +67,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def table_plans(monkeypatch):
+    """run this test on the committed launch plans (mimic_amd/plans_gfx950.json) wherever the table holds the triple -- the kernels
+    bench.py and a training run launch for the BASELINE shapes -- and on the static heuristic elsewhere; nothing is timed"""
+    from mimic_amd import ops
+    monkeypatch.setattr(ops, "TABLE_ONLY", True)
+    ops.clear_plans()
+    before = dict(ops._plan_sources)
+    yield lambda: {k: ops._plan_sources[k] - before[k] for k in before}
+    ops.clear_plans()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -99,6 +99,11 @@ def test_committed_plan_table_is_well_formed():
     assert found
     found, _ = ops._table_plan(("fwd", ops.Geom(3, 32, 32, 64, 64, 64, 128, 4, 4, 2, 2, 1, 1, False), False, False, True))
     assert not found
+    # conv2 of rb1 in the training step: dropout mask + statistics + residual mix; without dropout (eval, or dropout disabled)
+    # the same launch has no mask -- the table's plan for the masked form is used
+    masked = ops._table_plan(("fwd", g, False, True, True, "mix"))
+    unmasked = ops._table_plan(("fwd", g, False, False, True, "mix"))
+    assert masked[0] and unmasked[0] and (masked[1].tile, masked[1].split) == (unmasked[1].tile, unmasked[1].split)
 
 
 def test_split_bf16_switch_maps_committed_plans_back(monkeypatch):

@@ -502,7 +502,7 @@ def test_small_model_bf16_vs_oracle():
     check_bf16_case("small_bf16_eval", grads=False)
 
 
-def test_c3_full_size_bf16():
+def test_c3_full_size_bf16(table_plans):
     """BASELINE config #3 exactly: 128 px, class_dim 128, B = 256, bf16 -- forward scalars against the bf16-mode oracle and
     the REFERENCE's fp32 run, EVERY parameter gradient against both (fixture G7 c3_b256_bf16: the CPU passes at B = 256 ran
     in the build container, oracle/gen_g7.py), then three Adam steps (finite gradients, decreasing loss)."""
@@ -510,7 +510,7 @@ def test_c3_full_size_bf16():
     _three_steps(exp, cfg, 256, seed=92)
 
 
-def test_c5_full_size_bf16_and_fp32():
+def test_c5_full_size_bf16_and_fp32(table_plans):
     """BASELINE config #5 exactly: 256 px (the stride-4 block), class_dim 256, B = 32: the bf16 family's forward scalars and
     every parameter gradient (fixture G7 c5_b32_bf16), and the fp32 family's forward scalars on the same inputs against the
     reference's fp32 run (only B = 4 had run)."""
