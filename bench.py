@@ -54,7 +54,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 
 def _on_bf16_pipe(kernel_name: str) -> bool:
     """fp32-family kernels whose products run on the bf16 matrix pipe (csrc/conv_gemm_glds.inc, EMU = 1: plan tiles 16..19 /
-    wgrad tiles 7, 8) -- their template name ends with ', 1>'"""
+    wgrad tiles 7, 8: their template name ends with ', 1>'; wgrad tiles 9, 10: wgrad_parity_f32_kernel)"""
+    if kernel_name.startswith("wgrad_parity_f32_kernel<"):     # (fp32 wgrad tiles 9 / 10: always on the bf16 pipe)
+        return True
     return ("gather_gemm_f32_glds_kernel<" in kernel_name or "wgrad_gemm_f32_glds_kernel<" in kernel_name) and kernel_name.endswith(", 1>")
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
