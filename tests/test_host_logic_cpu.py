@@ -456,3 +456,37 @@ def test_token_likelihood_gradient_side_channel(monkeypatch):
             if p.grad is not None:
                 err = (grads[extra][1][n] - p.grad).abs().max().item()
                 assert err <= 1e-4 * max(p.grad.abs().max().item(), 1e-1), (n, err, p.grad.abs().max().item())   # (analytically-zero biases hold 1e-7 noise)
+
+
+def test_three_way_bf16_split_is_exact_and_six_terms_suffice():
+    """The arithmetic behind the fp32 plan tiles 16..19 / weight-gradient tiles 7..10 (csrc/conv_gemm_glds.inc, split3_pair),
+    restated with torch's round-to-nearest-even bf16 cast: every finite fp32 a splits EXACTLY into three bf16 numbers
+    h = bf16(a), m = bf16(a - h), l = a - h - m (l needs no rounding), and the six partial products the kernels issue
+    (hh, hm, mh, mm, hl, lh) miss the exact product a b by at most 2^-22 |a b| (the three dropped terms; typically 2^-28) --
+    the same order as ONE fp32 rounding of the product (2^-24), which the split form never commits."""
+    import torch
+    gen = torch.Generator().manual_seed(77)
+    n = 1 << 20
+    def wide():
+        return torch.randn(n, generator=gen) * torch.exp2(torch.randint(-60, 61, (n,), generator=gen).float())
+    def split(a):
+        h = a.to(torch.bfloat16).float()
+        r = a - h                       # exact: at most 16 significant bits
+        m = r.to(torch.bfloat16).float()
+        l = r - m                       # exact: at most 8 significant bits
+        assert torch.equal(l.to(torch.bfloat16).float(), l), "l is not a bf16 number"
+        assert torch.equal((h.double() + m.double() + l.double()), a.double()), "h + m + l != a"
+        assert (r.abs() <= a.abs() * 2.0 ** -8).all() and (l.abs() <= a.abs() * 2.0 ** -16).all()
+        return h.double(), m.double(), l.double()
+    a, b = wide(), wide()
+    a[:1000] = 0.0
+    b[500:1500] = torch.tensor(1.0)
+    ah, am, al = split(a)
+    bh, bm, bl = split(b)
+    six = ah * bh + ah * bm + am * bh + am * bm + ah * bl + al * bh
+    exact = a.double() * b.double()
+    nz = exact != 0
+    rel = ((six - exact).abs()[nz] / exact.abs()[nz])
+    assert rel.max().item() <= 2.0 ** -22, rel.max().item()
+    assert rel.median().item() <= 2.0 ** -26, rel.median().item()
+    assert torch.equal(six[~nz], exact[~nz])
