@@ -251,7 +251,12 @@ _TUNE_REPS = int(os.environ.get("MOPOE_TUNE_REPS", "3"))
 # (a GPU that has just left idle ranks candidates differently from steady state).  Default 0 = tune at first use,
 # so that one warm-up step settles every plan.
 TUNE_AFTER_CALLS = int(os.environ.get("MOPOE_TUNE_AFTER_CALLS", "0"))
-TUNE_ALPHA = float(os.environ.get("MOPOE_TUNE_ALPHA", "1.0"))
+# Objective of the ranking: duration x (alpha + (1 - alpha) x the fraction of the chip the launch occupies).  1.0 = isolated
+# latency alone.  0.7 (default since round 4): inside the step three networks' kernels share the chip, and a plan that is a few
+# per cent slower alone but leaves CUs (and LDS) to the other branches wins there -- force-tuned bench.py, same box:
+# C2 6 305 / 6 312 (1.0) -> 6 444 / 6 451 / 6 473 (0.7), 6 440 (0.6), 6 342 (0.5), 6 018 (0.3); C5 5 100 -> 5 239; c2d128 2 671 -> 2 707;
+# C3 22 677 -> 22 761
+TUNE_ALPHA = float(os.environ.get("MOPOE_TUNE_ALPHA", "0.7"))
 # tiles 8..11 (LDS-free kernel) among the tuner's candidates: off by default -- they win on many small layers when timed
 # alone but the step as a whole (three modalities' kernels running side by side) is not faster with them
 DIRECT_TILES = os.environ.get("MOPOE_DIRECT_TILES", "0") != "0"
