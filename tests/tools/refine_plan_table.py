@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--report", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--skip", type=int, default=0, help="leave out the N costliest triples (examined by an earlier pass)")
     ap.add_argument("--alts", type=int, default=3)
     ap.add_argument("--gain", type=float, default=0.003)
     ap.add_argument("--steps", type=int, default=80)
@@ -75,7 +76,7 @@ def main():
     keys = [k for k in report if report[k].get("candidates") and k in ops._plan_table and ops._plan_table[k] is not None]
     keys.sort(key=lambda k: -(report[k].get("chosen_us") or 0.0))
     changed = {}
-    for k in keys[:args.top]:
+    for k in keys[args.skip:args.skip + args.top]:
         cur = tuple(ops._plan_table[k])
         cands = sorted(report[k]["candidates"].items(), key=lambda kv: kv[1])
         best_us = cands[0][1]
