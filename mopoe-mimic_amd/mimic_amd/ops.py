@@ -451,8 +451,9 @@ def _wgrad_candidates(g: Geom, bf16: bool = False, plain_operand: bool = False):
                 continue
             tiles = -(-cg // 64) * (csm // cs) * 4
             seen = set()
-            for target in (64, 128, 192, 256, 384, 512, 1024):
-                s = max(1, min(-(-target // tiles), ntiles))
+            # (one block per CU: the largest split that still fits ONE round of 256 blocks is usually the best -- rb2 of
+            # config #2, 24 channel-tile x class blocks: split 10 = 240 blocks 92 us, split 8 = 192 blocks 105, split 11 = 264 blocks 148)
+            for s in [max(1, min(256 // tiles, ntiles))] + [max(1, min(-(-target // tiles), ntiles)) for target in (64, 128, 192, 256, 384, 512, 1024)]:
                 if s not in seen:
                     seen.add(s)
                     cands[(tile, s)] = min(1.0, tiles * s / 256)

@@ -42,7 +42,7 @@ for name, g in GEOMS:
     print(f"== {name}  N={g.N}  {flops / 1e9:.1f} GF")
     for tile in (2, 9, 10):
         row = []
-        for sp in (4, 8, 16, 32, 64, 128, 256):
+        for sp in (4, 8, 10, 12, 16, 20, 32, 42, 64, 128, 256):
             try:
                 with ops.force_plan(tile, sp):
                     t = timed(lambda: ops.conv_wgrad(x, dy, g))
